@@ -1,0 +1,232 @@
+/*
+ * seabreeze_hip.h -- C ABI of libseabreeze_hip.so, the MI355X (gfx950) implementation
+ * of the sea-breeze trigger diagnostic's hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.
+ * The Fortran host modules (fortran/ *.f90, ISO_C_BINDING) and the f2py-surface Python
+ * module (python_wrapper/) bind exactly these entry points; INTEGRATION.md shows the
+ * reference-side stubs.  Paths cited as "ref:" are relative to the reference tree
+ * (antarcticrainforest/seabreeze_param).
+ *
+ * Conventions
+ *   - Arrays are Fortran order, longitude fastest: f(lon, lat[, lev]); contiguous.
+ *   - Two precisions: _f32 (default REAL) and _f64 (REAL under -fdefault-real-8),
+ *     mirroring how the reference picks its working precision at compile time.
+ *   - Entry points without a suffix take HOST pointers (drop-in semantics: the caller
+ *     owns every array, ref: SURVEY.md §8(b) "Ownership"); the library stages them
+ *     through device buffers it owns.  `_dev` entry points take DEVICE pointers and
+ *     enqueue on `stream` (a hipStream_t passed as void*; NULL = the context's own
+ *     stream) without synchronising -- this is what a GPU-resident host model and
+ *     bench.py use.
+ *   - Every function returns SB_OK (0) or an sb_status; sb_last_error() gives text.
+ *     The reference has no error reporting on this path (generic + wrapper) and an
+ *     `error` out-argument in the UM copy (ref: UM/vn10.7/sea_breeze_diag.F90:102,
+ *     198-202); the Fortran modules map a non-zero status to `error stop` / `error`.
+ *   - There is NO CPU fallback: without a usable gfx950 device sb_create fails with
+ *     SB_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef SEABREEZE_HIP_H
+#define SEABREEZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sb_ctx sb_ctx;
+
+typedef enum sb_status {
+    SB_OK = 0,
+    SB_ERR_ARG = 1,        /* bad dimension / NULL pointer / unsupported combination   */
+    SB_ERR_HIP = 2,        /* a HIP runtime call failed                                */
+    SB_ERR_NO_DEVICE = 3,  /* no gfx950 device visible                                 */
+    SB_ERR_ALLOC = 4,      /* device workspace allocation failed                       */
+    SB_ERR_COMM = 5        /* RCCL halo exchange failed / not initialised              */
+} sb_status;
+
+/* Window / neighbour index rule at the domain edge. */
+typedef enum sb_boundary {
+    /* lat clamp, lon `max(1, modulo(jj, nlons))` -- reproduces the f2py kernels
+       verbatim, including the lon quirk (ref: python_wrapper/seabreezediag/
+       seabreeze_diag_python.f90:201-202, sobel.f90:67-68) */
+    SB_BND_WRAPPER = 0,
+    /* lat clamp, true periodic lon: the single-domain reading of the generic code's
+       unguarded window (ref: generic/sea_breeze_diag.f90:198-200)                    */
+    SB_BND_GLOBAL = 1,
+    /* raw reads into `halo` ghost cells supplied by the caller around theta, mask, z
+       and sigma (UM-style bounds 1-h:n+h, ref: UM/vn10.7/sea_breeze_diag.F90:94-99,
+       241-243); the ghost cells are what swap_bounds fills                            */
+    SB_BND_HALO = 2
+} sb_boundary;
+
+/* Tunables of the trigger in SI units (ref: generic/sea_breeze_diag.f90:127-138). */
+typedef struct sb_tunables {
+    double target_plev_pa;   /* 70000.  */
+    double thresh_wind;      /* 11.     */
+    double thresh_winddir;   /* 90.     */
+    double thresh_windch;    /* 5.      */
+    double thresh_thc;       /* 0.75    */
+    double target_time_s;    /* 21600.  */
+    double maxdist_km;       /* 180.    */
+} sb_tunables;
+
+/* -------------------------------------------------------------------------------- */
+/* context                                                                          */
+/* -------------------------------------------------------------------------------- */
+int  sb_create(sb_ctx **ctx, int device);            /* device < 0: current device   */
+int  sb_destroy(sb_ctx *ctx);
+const char *sb_last_error(const sb_ctx *ctx);        /* ctx may be NULL               */
+const char *sb_version(void);
+void sb_default_tunables(sb_tunables *t);
+/* Expected largest search radius of the land/sea window (selects the LDS tile halo;
+   results never depend on it -- cells that need more take a global-memory path).   */
+int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
+/* Counters of the last diag call: [0] band cells, [1] cells that left the LDS path,
+   [2] cells whose search found only one class (result NaN; the reference loops
+   forever there, ref: generic/sea_breeze_diag.f90:191-214), [3] max radius used.
+   Synchronises the context's stream.                                                */
+int  sb_last_counters(sb_ctx *ctx, long long counters[4]);
+int  sb_synchronize(sb_ctx *ctx);
+
+/* -------------------------------------------------------------------------------- */
+/* seabreeze_diag -- host-model flavour                                              */
+/* replaces: subroutine seabreeze_diag(timestep, timestep_number, p, u, v, theta,   */
+/*           mask, z, sigma, windspeed, winddir, thc, sb_con)                        */
+/*           ref: generic/sea_breeze_diag.f90:55-271                                 */
+/* p,u,v: (nx,ny,nz).  theta,mask,z,sigma: (nx+2*halo, ny+2*halo), interior at       */
+/* offset `halo` (halo must be 0 unless bnd == SB_BND_HALO).                         */
+/* windspeed,winddir,thc,sb_con: (nx,ny), updated in place.                          */
+/* tun == NULL selects the reference's compile-time constants.                       */
+/* -------------------------------------------------------------------------------- */
+int sb_seabreeze_diag_f64(sb_ctx *ctx, double timestep_s, int timestep_number,
+                          int nx, int ny, int nz, int halo, int bnd,
+                          const double *p, const double *u, const double *v,
+                          const double *theta, const double *mask, const double *z,
+                          const double *sigma, double *windspeed, double *winddir,
+                          double *thc, double *sb_con, const sb_tunables *tun);
+int sb_seabreeze_diag_f32(sb_ctx *ctx, float timestep_s, int timestep_number,
+                          int nx, int ny, int nz, int halo, int bnd,
+                          const float *p, const float *u, const float *v,
+                          const float *theta, const float *mask, const float *z,
+                          const float *sigma, float *windspeed, float *winddir,
+                          float *thc, float *sb_con, const sb_tunables *tun);
+int sb_seabreeze_diag_f64_dev(sb_ctx *ctx, double timestep_s, int timestep_number,
+                          int nx, int ny, int nz, int halo, int bnd,
+                          const double *p, const double *u, const double *v,
+                          const double *theta, const double *mask, const double *z,
+                          const double *sigma, double *windspeed, double *winddir,
+                          double *thc, double *sb_con, const sb_tunables *tun,
+                          void *stream);
+int sb_seabreeze_diag_f32_dev(sb_ctx *ctx, float timestep_s, int timestep_number,
+                          int nx, int ny, int nz, int halo, int bnd,
+                          const float *p, const float *u, const float *v,
+                          const float *theta, const float *mask, const float *z,
+                          const float *sigma, float *windspeed, float *winddir,
+                          float *thc, float *sb_con, const sb_tunables *tun,
+                          void *stream);
+
+/* -------------------------------------------------------------------------------- */
+/* diag -- f2py-surface flavour (whole global grid, 1-D p, packed output)            */
+/* replaces: subroutine diag(timestep_number, p, z, std, theta, v, u, cdist,         */
+/*           windspeed, winddir, thc, target_plev, thresh_wind, thresh_winddir,      */
+/*           thresh_windch, thresh_thc, target_time, maxdist, timestep, nps, nlons,  */
+/*           nlats, output)                                                          */
+/*           ref: python_wrapper/seabreezediag/seabreeze_diag_python.f90:49-285      */
+/* Units as at that surface: target_plev hPa, target_time h, timestep min; unlike    */
+/* the reference they are NOT overwritten in place (:146-148).  Rows 1..nlats-1 are  */
+/* processed, row nlats of `output` is left untouched (:165).  windspeed, winddir,   */
+/* thc are updated in place like the reference's dummies.                            */
+/* output: (nlons,nlats,4) = sb_con, t0, windspeed, winddir (:277-280).              */
+/* -------------------------------------------------------------------------------- */
+int sb_diag_f64(sb_ctx *ctx, int timestep_number, const double *p, const double *z,
+                const double *std, const double *theta, const double *v, const double *u,
+                const double *cdist, double *windspeed, double *winddir, double *thc,
+                double target_plev, double thresh_wind, double thresh_winddir,
+                double thresh_windch, double thresh_thc, double target_time,
+                double maxdist, double timestep, int nps, int nlons, int nlats,
+                double *output);
+int sb_diag_f32(sb_ctx *ctx, int timestep_number, const float *p, const float *z,
+                const float *std, const float *theta, const float *v, const float *u,
+                const float *cdist, float *windspeed, float *winddir, float *thc,
+                float target_plev, float thresh_wind, float thresh_winddir,
+                float thresh_windch, float thresh_thc, float target_time,
+                float maxdist, float timestep, int nps, int nlons, int nlats,
+                float *output);
+int sb_diag_f64_dev(sb_ctx *ctx, int timestep_number, const double *p, const double *z,
+                const double *std, const double *theta, const double *v, const double *u,
+                const double *cdist, double *windspeed, double *winddir, double *thc,
+                double target_plev, double thresh_wind, double thresh_winddir,
+                double thresh_windch, double thresh_thc, double target_time,
+                double maxdist, double timestep, int nps, int nlons, int nlats,
+                double *output, void *stream);
+int sb_diag_f32_dev(sb_ctx *ctx, int timestep_number, const float *p, const float *z,
+                const float *std, const float *theta, const float *v, const float *u,
+                const float *cdist, float *windspeed, float *winddir, float *thc,
+                float target_plev, float thresh_wind, float thresh_winddir,
+                float thresh_windch, float thresh_thc, float target_time,
+                float maxdist, float timestep, int nps, int nlons, int nlats,
+                float *output, void *stream);
+
+/* -------------------------------------------------------------------------------- */
+/* sigmoid                                                                           */
+/* replaces: subroutine sigmoid(ary, sm)  ref: generic/sea_breeze_diag.f90:457-481,  */
+/*           seabreeze_diag_python.f90:287-311                                       */
+/* -------------------------------------------------------------------------------- */
+int sb_sigmoid_f64(sb_ctx *ctx, int nlons, int nlats, const double *ary, double *sm);
+int sb_sigmoid_f32(sb_ctx *ctx, int nlons, int nlats, const float *ary, float *sm);
+int sb_sigmoid_f64_dev(sb_ctx *ctx, int nlons, int nlats, const double *ary, double *sm, void *stream);
+int sb_sigmoid_f32_dev(sb_ctx *ctx, int nlons, int nlats, const float *ary, float *sm, void *stream);
+
+/* -------------------------------------------------------------------------------- */
+/* get_edges -- coastline by binary 3x3 Sobel                                        */
+/* replaces: get_edges(lsm, ci, nlons, nlats, coast)  ref: sobel.f90:19-89 (rule 0)  */
+/*           get_edges(mask, icefrac, landfrac, halo_size)                           */
+/*                                    ref: generic/sea_breeze_diag.f90:273-373 (rule 1) */
+/* rule 0: land <=> lsm+ci > 0.4; rule 1: ice-aware two-branch mask (:325-337).      */
+/* -------------------------------------------------------------------------------- */
+int sb_get_edges_f64(sb_ctx *ctx, int nlons, int nlats, const double *lsm, const double *ci,
+                     int rule, int bnd, double *coast);
+int sb_get_edges_f32(sb_ctx *ctx, int nlons, int nlats, const float *lsm, const float *ci,
+                     int rule, int bnd, float *coast);
+int sb_get_edges_f64_dev(sb_ctx *ctx, int nlons, int nlats, const double *lsm, const double *ci,
+                     int rule, int bnd, double *coast, void *stream);
+int sb_get_edges_f32_dev(sb_ctx *ctx, int nlons, int nlats, const float *lsm, const float *ci,
+                     int rule, int bnd, float *coast, void *stream);
+
+/* -------------------------------------------------------------------------------- */
+/* get_dist -- signed great-circle distance (km) to the nearest coast cell           */
+/* replaces: get_dist(coast, mask, lon, lat, nlons, nlats, maxdist, cdist)           */
+/*                                   ref: sobel.f90:91-193                           */
+/*           get_dist(coast, landfrac, lon, lat, maxdist, cdist, halo_size)          */
+/*                                   ref: generic/sea_breeze_diag.f90:375-455        */
+/* kwin < 0: window half-width from the 70-degree grid spacing (sobel.f90:129-137);  */
+/* kwin >= 0: fixed +-kwin cells (the generic/UM halo width, generic :422,425).      */
+/* lon, lat: HOST pointers in every variant (tiny vectors; the window size is        */
+/* derived from them on the host).                                                   */
+/* -------------------------------------------------------------------------------- */
+int sb_get_dist_f64(sb_ctx *ctx, int nlons, int nlats, const double *coast, const double *mask,
+                    const double *lon, const double *lat, double maxdist, int kwin, double *cdist);
+int sb_get_dist_f32(sb_ctx *ctx, int nlons, int nlats, const float *coast, const float *mask,
+                    const float *lon, const float *lat, float maxdist, int kwin, float *cdist);
+int sb_get_dist_f64_dev(sb_ctx *ctx, int nlons, int nlats, const double *coast, const double *mask,
+                    const double *lon, const double *lat, double maxdist, int kwin, double *cdist,
+                    void *stream);
+int sb_get_dist_f32_dev(sb_ctx *ctx, int nlons, int nlats, const float *coast, const float *mask,
+                    const float *lon, const float *lat, float maxdist, int kwin, float *cdist,
+                    void *stream);
+/* The half-width sb_get_dist would pick for kwin < 0. */
+int sb_dist_window_f64(int nlons, int nlats, const double *lon, const double *lat, double maxdist, int *k);
+int sb_dist_window_f32(int nlons, int nlats, const float *lon, const float *lat, float maxdist, int *k);
+
+/* -------------------------------------------------------------------------------- */
+/* get_threads  ref: sobel.f90:195-206 (OpenMP thread count there; here the number   */
+/* of visible HIP devices -- the unit of parallelism a caller can spread bands over) */
+/* -------------------------------------------------------------------------------- */
+int sb_get_threads(int *nt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEABREEZE_HIP_H */

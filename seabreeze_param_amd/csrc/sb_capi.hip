@@ -1,0 +1,550 @@
+// sb_capi.hip -- the C ABI of libseabreeze_hip.so (see include/seabreeze_hip.h).
+//
+// Host-pointer entry points stage through device buffers owned by the context and
+// synchronise before returning; `_dev` entry points only enqueue.  There is no CPU
+// fallback anywhere in this file: no device => SB_ERR_NO_DEVICE.
+#include "../../include/seabreeze_hip.h"
+#include "sb_launch.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;   // errors raised without a context
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct sb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int radius_hint = 16;
+    // workspace (grow-only)
+    DevBuf t0, bandbits, clsbits, tiles, vecs;
+    Moments *partials = nullptr;
+    unsigned int *ticket = nullptr;
+    void *stats = nullptr;      // 4 x double
+    int *counters = nullptr;    // 2 ints
+    // staging buffers for the host-pointer entry points
+    std::vector<DevBuf> stage;
+    // geometry of the last diag call (for sb_last_counters)
+    Geo last_g{};
+    int last_tiles = 0;
+    bool have_last = false;
+};
+
+namespace {
+
+int fail(sb_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_err = msg;
+    return code;
+}
+
+int hipfail(sb_ctx *c, hipError_t e, const char *what) {
+    return fail(c, SB_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(c, call)                                         \
+    do {                                                        \
+        hipError_t e__ = (call);                                \
+        if (e__ != hipSuccess) return hipfail((c), e__, #call); \
+    } while (0)
+
+int ensure(sb_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return SB_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, SB_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b.cap = bytes;
+    return SB_OK;
+}
+
+template <typename T>
+Geo make_geo(int nx, int ny, int h, int bnd, int rows) {
+    Geo g;
+    g.nx = nx; g.ny = ny; g.h = h;
+    g.nxh = nx + 2 * h; g.nyh = ny + 2 * h;
+    g.nw = (g.nxh + 63) / 64;
+    g.bnd = bnd; g.rows = rows;
+    return g;
+}
+
+int pick_halo(const sb_ctx *c) {
+    int r = c->radius_hint;
+    if (r <= 8) return 8;
+    if (r <= 16) return 16;
+    return SB_MAX_LDS_HALO;
+}
+
+// Prepare workspace + job; enqueue the four kernels of one diag call.
+template <typename T>
+int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st) {
+    const Geo &g = job.g;
+    const size_t ncell = (size_t)g.nxh * g.nyh;
+    const size_t nbits = (size_t)g.nyh * g.nw * sizeof(uint64_t);
+    int rc;
+    if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
+    if ((rc = ensure(c, c->bandbits, nbits))) return rc;
+    if ((rc = ensure(c, c->clsbits, nbits))) return rc;
+    const int H = pick_halo(c);
+    int tx, ty;
+    sb_thc_tiles<T>(g.nx, g.rows, H, tx, ty);
+    if ((rc = ensure(c, c->tiles, (size_t)tx * ty * sizeof(int)))) return rc;
+    job.t0 = (T *)c->t0.p;
+    job.bandbits = (uint64_t *)c->bandbits.p;
+    job.clsbits = (uint64_t *)c->clsbits.p;
+    job.stats = (const T *)c->stats;
+    job.tile_nnmax = (int *)c->tiles.p;
+    job.counters = c->counters;
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, 2 * sizeof(int), st));
+    HIPCHK(c, sb_launch_diag<T>(job, H, c->partials, c->ticket, (T *)c->stats, st));
+    c->last_g = g;
+    c->last_tiles = tx * ty;
+    c->have_last = true;
+    return SB_OK;
+}
+
+template <typename T>
+int check_dims(sb_ctx *c, int nx, int ny, int nz, int halo, int bnd) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || nz < 1) return fail(c, SB_ERR_ARG, "nx, ny, nz must be >= 1");
+    if (bnd < 0 || bnd > 2) return fail(c, SB_ERR_ARG, "unknown boundary rule");
+    if (halo < 0 || (halo > 0 && bnd != SB_BND_HALO)) return fail(c, SB_ERR_ARG, "halo > 0 needs SB_BND_HALO");
+    if ((double)(nx + 2 * halo) * (double)(ny + 2 * halo) > 2.0e9) return fail(c, SB_ERR_ARG, "grid too large");
+    return SB_OK;
+}
+
+template <typename T>
+int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, int bnd, const T *p,
+                       const T *u, const T *v, const T *theta, const T *mask, const T *z, const T *sigma, T *ws,
+                       T *wd, T *thc, T *sb_con, const sb_tunables *tun, void *stream) {
+    int rc = check_dims<T>(c, nx, ny, nz, halo, bnd);
+    if (rc) return rc;
+    if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    sb_tunables d;
+    sb_default_tunables(&d);
+    if (tun) d = *tun;
+    DiagJob<T> job{};
+    job.g = make_geo<T>(nx, ny, halo, bnd, ny);
+    job.nz = nz;
+    job.flavour = SB_FLAVOUR_GENERIC;
+    job.tn = tn;
+    // modulo(real(timestep_number)*timestep, target_time) < 0.0001   ref: generic/sea_breeze_diag.f90:264
+    const T period = (T)d.target_time_s;
+    job.refresh = sb_modulo<T>((T)tn * timestep_s, period) < T(0.0001) ? 1 : 0;
+    job.target_plev = (T)d.target_plev_pa; job.thr_wind = (T)d.thresh_wind; job.thr_dir = (T)d.thresh_winddir;
+    job.thr_ch = (T)d.thresh_windch; job.thr_thc = (T)d.thresh_thc; job.maxdist = (T)d.maxdist_km;
+    job.fill = T(0);                                              // ref :176
+    job.p = p; job.u = u; job.v = v; job.theta = theta; job.mask = mask; job.z = z; job.sigma = sigma;
+    job.ws = ws; job.wd = wd; job.thc = thc; job.sb_con = sb_con; job.out = nullptr;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return run_diag<T>(c, job, st);
+}
+
+template <typename T>
+int diag_dev(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T *theta, const T *v, const T *u,
+             const T *cdist, T *ws, T *wd, T *thc, T target_plev, T thresh_wind, T thresh_winddir, T thresh_windch,
+             T thresh_thc, T target_time, T maxdist, T timestep, int nps, int nlons, int nlats, T *output,
+             void *stream) {
+    int rc = check_dims<T>(c, nlons, nlats, nps, 0, SB_BND_WRAPPER);
+    if (rc) return rc;
+    if (!p || !z || !std_ || !theta || !v || !u || !cdist || !ws || !wd || !thc || !output)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    DiagJob<T> job{};
+    job.g = make_geo<T>(nlons, nlats, 0, SB_BND_WRAPPER, nlats - 1);   // ref: seabreeze_diag_python.f90:165
+    job.nz = nps;
+    job.flavour = SB_FLAVOUR_WRAPPER;
+    job.tn = tn;
+    // unit conversions in the working precision, ref :146-148
+    const T dt_s = timestep * T(60.);
+    const T period = target_time * (T(60.) * T(60.));
+    job.target_plev = target_plev * T(100.);
+    job.refresh = sb_modulo<T>((T)tn * dt_s, period) < T(0.0001) ? 1 : 0;   // ref :271
+    job.thr_wind = thresh_wind; job.thr_dir = thresh_winddir; job.thr_ch = thresh_windch;
+    job.thr_thc = thresh_thc; job.maxdist = maxdist;
+    job.fill = T(2.0E20);                                         // ref :173
+    job.p = p; job.u = u; job.v = v; job.theta = theta; job.mask = cdist; job.z = z; job.sigma = std_;
+    job.ws = ws; job.wd = wd; job.thc = thc; job.sb_con = nullptr; job.out = output;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (job.g.rows < 1) return SB_OK;                             // nlats == 1: the reference loop is empty
+    return run_diag<T>(c, job, st);
+}
+
+// ---- host staging helpers ----------------------------------------------------------
+struct Stager {
+    sb_ctx *c;
+    size_t next = 0;
+    int rc = SB_OK;
+    explicit Stager(sb_ctx *ctx) : c(ctx) {}
+    template <typename T>
+    T *in(const T *host, size_t n) {       // upload
+        T *d = out<T>(n);
+        if (rc || !d) return nullptr;
+        hipError_t e = hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = hipfail(c, e, "hipMemcpyAsync H2D");
+        return d;
+    }
+    template <typename T>
+    T *out(size_t n) {                     // device scratch only
+        if (rc) return nullptr;
+        if (next >= c->stage.size()) c->stage.resize(next + 1);
+        DevBuf &b = c->stage[next++];
+        rc = ensure(c, b, n * sizeof(T) > 0 ? n * sizeof(T) : 8);
+        return rc ? nullptr : (T *)b.p;
+    }
+    template <typename T>
+    void back(T *host, const T *dev, size_t n) {
+        if (rc) return;
+        hipError_t e = hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = hipfail(c, e, "hipMemcpyAsync D2H");
+    }
+    int finish() {
+        if (rc) return rc;
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hipfail(c, e, "hipStreamSynchronize");
+        return SB_OK;
+    }
+};
+
+template <typename T>
+int seabreeze_diag_host(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, int bnd, const T *p,
+                        const T *u, const T *v, const T *theta, const T *mask, const T *z, const T *sigma, T *ws,
+                        T *wd, T *thc, T *sb_con, const sb_tunables *tun) {
+    int rc = check_dims<T>(c, nx, ny, nz, halo, bnd);
+    if (rc) return rc;
+    if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, n2h = (size_t)(nx + 2 * halo) * (ny + 2 * halo);
+    Stager s(c);
+    T *dp = s.in(p, n3), *du = s.in(u, n3), *dv = s.in(v, n3);
+    T *dth = s.in(theta, n2h), *dm = s.in(mask, n2h), *dz = s.in(z, n2h), *dsg = s.in(sigma, n2h);
+    T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2), *dsb = s.in(sb_con, n2);
+    if (s.rc) return s.rc;
+    rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, bnd, dp, du, dv, dth, dm, dz, dsg, dws, dwd,
+                               dthc, dsb, tun, nullptr);
+    if (rc) return rc;
+    s.back(ws, dws, n2); s.back(wd, dwd, n2); s.back(thc, dthc, n2); s.back(sb_con, dsb, n2);
+    return s.finish();
+}
+
+template <typename T>
+int diag_host(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T *theta, const T *v, const T *u,
+              const T *cdist, T *ws, T *wd, T *thc, T target_plev, T thresh_wind, T thresh_winddir, T thresh_windch,
+              T thresh_thc, T target_time, T maxdist, T timestep, int nps, int nlons, int nlats, T *output) {
+    int rc = check_dims<T>(c, nlons, nlats, nps, 0, SB_BND_WRAPPER);
+    if (rc) return rc;
+    if (!p || !z || !std_ || !theta || !v || !u || !cdist || !ws || !wd || !thc || !output)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    const size_t n2 = (size_t)nlons * nlats, n3 = n2 * nps;
+    Stager s(c);
+    T *dp = s.in(p, (size_t)nps), *dz = s.in(z, n2), *dsd = s.in(std_, n2), *dth = s.in(theta, n2);
+    T *dv = s.in(v, n3), *du = s.in(u, n3), *dcd = s.in(cdist, n2);
+    T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2);
+    T *dout = s.in(output, 4 * n2);          // row nlats is left as the caller passed it
+    if (s.rc) return s.rc;
+    rc = diag_dev<T>(c, tn, dp, dz, dsd, dth, dv, du, dcd, dws, dwd, dthc, target_plev, thresh_wind, thresh_winddir,
+                     thresh_windch, thresh_thc, target_time, maxdist, timestep, nps, nlons, nlats, dout, nullptr);
+    if (rc) return rc;
+    s.back(ws, dws, n2); s.back(wd, dwd, n2); s.back(thc, dthc, n2); s.back(output, dout, 4 * n2);
+    return s.finish();
+}
+
+template <typename T>
+int sigmoid_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, c->ticket, (T *)c->stats, st));
+    HIPCHK(c, sb_launch_sigmoid_apply<T>(ary, sm, (size_t)nx * ny, (const T *)c->stats, st));
+    return SB_OK;
+}
+
+template <typename T>
+int sigmoid_host(sb_ctx *c, int nx, int ny, const T *ary, T *sm) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
+    const size_t n = (size_t)nx * ny;
+    Stager s(c);
+    T *da = s.in(ary, n), *ds = s.out<T>(n);
+    if (s.rc) return s.rc;
+    int rc = sigmoid_dev<T>(c, nx, ny, da, ds, nullptr);
+    if (rc) return rc;
+    s.back(sm, ds, n);
+    return s.finish();
+}
+
+template <typename T>
+int get_edges_dev(sb_ctx *c, int nx, int ny, const T *lsm, const T *ci, int rule, int bnd, T *coast, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !lsm || !ci || !coast) return fail(c, SB_ERR_ARG, "bad get_edges arguments");
+    if (rule < 0 || rule > 1) return fail(c, SB_ERR_ARG, "unknown mask rule");
+    if (bnd != SB_BND_WRAPPER && bnd != SB_BND_GLOBAL) return fail(c, SB_ERR_ARG, "get_edges: boundary must be WRAPPER or GLOBAL");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, sb_launch_edges<T>(lsm, ci, coast, nx, ny, rule, bnd, st));
+    return SB_OK;
+}
+
+template <typename T>
+int get_edges_host(sb_ctx *c, int nx, int ny, const T *lsm, const T *ci, int rule, int bnd, T *coast) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !lsm || !ci || !coast) return fail(c, SB_ERR_ARG, "bad get_edges arguments");
+    const size_t n = (size_t)nx * ny;
+    Stager s(c);
+    T *dl = s.in(lsm, n), *dc = s.in(ci, n), *dco = s.out<T>(n);
+    if (s.rc) return s.rc;
+    int rc = get_edges_dev<T>(c, nx, ny, dl, dc, rule, bnd, dco, nullptr);
+    if (rc) return rc;
+    s.back(coast, dco, n);
+    return s.finish();
+}
+
+// window half-width from the grid spacing at 70 degrees, ref: sobel.f90:129-137
+template <typename T>
+int dist_window(int nx, int ny, const T *lon, const T *lat, T maxdist, int *k) {
+    if (nx < 2 || ny < 2 || !lon || !lat || !k) return fail(nullptr, SB_ERR_ARG, "bad dist_window arguments");
+    const T R = T(6370.9989), pi = T(3.1415926), d2r = pi / T(180.0);
+    int tlat = 0;
+    T best = std::fabs(T(70) - lat[0]);
+    for (int i = 1; i < ny; ++i) {
+        const T a = std::fabs(T(70) - lat[i]);
+        if (a < best) { best = a; tlat = i; }
+    }
+    if (tlat + 1 >= ny) return fail(nullptr, SB_ERR_ARG, "latitude nearest 70 deg is the last row (the reference reads out of bounds there)");
+    const T p0 = d2r * lat[tlat], p1 = d2r * lat[tlat + 1];
+    const T dphi = p1 - p0, dlam = d2r * lon[1] - d2r * lon[0];
+    const T sp = std::sin(dphi / T(2)), sl = std::sin(dlam / T(2));
+    const T a = sp * sp + (std::cos(p1) * (std::cos(p0) * (sl * sl)));
+    const T dx = (R * T(2)) * std::atan2(std::sqrt(a), std::sqrt(T(1) - a));
+    *k = (int)(maxdist / dx);
+    return SB_OK;
+}
+
+template <typename T>
+int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const T *lon, const T *lat, T maxdist,
+                 int kwin, T *cdist, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !coast || !mask || !lon || !lat || !cdist)
+        return fail(c, SB_ERR_ARG, "bad get_dist arguments");
+    int k = kwin;
+    if (kwin < 0) {
+        int rc = dist_window<T>(nx, ny, lon, lat, maxdist, &k);
+        if (rc) { c->err = g_err; return rc; }
+    }
+    if ((size_t)(64 + 2 * k) * (SB_DIST_TY + 2 * k) > 64 * 1024)
+        return fail(c, SB_ERR_ARG, "get_dist: window too large for the LDS tile");
+    // phi = d2r*lat, folded lon in radians (ref: sobel.f90:130,165-174), host side: multiplies only
+    const T pi = T(3.1415926), d2r = pi / T(180.0);
+    std::vector<T> hv((size_t)nx + ny);
+    for (int i = 0; i < ny; ++i) hv[i] = d2r * lat[i];
+    for (int j = 0; j < nx; ++j) hv[ny + j] = (lon[j] > T(180)) ? d2r * (lon[j] - T(360.)) : d2r * lon[j];
+    int rc = ensure(c, c->vecs, hv.size() * sizeof(T));
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->vecs.p, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));   // hv is a local: the copy must land before it dies
+    const T *dphi = (const T *)c->vecs.p, *dlam = dphi + ny;
+    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, st));
+    // a distance field made here bounds the search radius of the following diag calls
+    c->radius_hint = k + 1;
+    return SB_OK;
+}
+
+template <typename T>
+int get_dist_host(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const T *lon, const T *lat, T maxdist,
+                  int kwin, T *cdist) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || !coast || !mask || !lon || !lat || !cdist)
+        return fail(c, SB_ERR_ARG, "bad get_dist arguments");
+    const size_t n = (size_t)nx * ny;
+    Stager s(c);
+    T *dco = s.in(coast, n), *dm = s.in(mask, n), *dcd = s.out<T>(n);
+    if (s.rc) return s.rc;
+    int rc = get_dist_dev<T>(c, nx, ny, dco, dm, lon, lat, maxdist, kwin, dcd, nullptr);
+    if (rc) return rc;
+    s.back(cdist, dcd, n);
+    return s.finish();
+}
+
+}  // namespace
+
+// ======================================================================================
+// extern "C"
+// ======================================================================================
+extern "C" {
+
+const char *sb_version(void) { return "seabreeze_hip 0.1.0 (gfx950)"; }
+
+const char *sb_last_error(const sb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+void sb_default_tunables(sb_tunables *t) {
+    if (!t) return;
+    t->target_plev_pa = 100 * 700.;
+    t->thresh_wind = 11.;
+    t->thresh_winddir = 90.;
+    t->thresh_windch = 5.;
+    t->thresh_thc = 0.75;
+    t->target_time_s = 6. * 60 * 60;
+    t->maxdist_km = 180.;
+}
+
+int sb_get_threads(int *nt) {
+    if (!nt) return fail(nullptr, SB_ERR_ARG, "null pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *nt = n;
+    return SB_OK;
+}
+
+int sb_create(sb_ctx **out, int device) {
+    if (!out) return fail(nullptr, SB_ERR_ARG, "null pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1)
+        return fail(nullptr, SB_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) return fail(nullptr, SB_ERR_ARG, "device index out of range");
+    if ((e = hipSetDevice(device)) != hipSuccess) return hipfail(nullptr, e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hipfail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SB_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    sb_ctx *c = new sb_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return hipfail(nullptr, e, "hipStreamCreate");
+    }
+    bool ok = hipMalloc((void **)&c->partials, SB_STATS_MAX_BLOCKS * sizeof(Moments)) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, sizeof(unsigned int)) == hipSuccess &&
+              hipMalloc(&c->stats, 4 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&c->counters, 2 * sizeof(int)) == hipSuccess &&
+              hipMemset(c->ticket, 0, sizeof(unsigned int)) == hipSuccess &&
+              hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess;
+    if (!ok) {
+        sb_destroy(c);
+        return fail(nullptr, SB_ERR_ALLOC, "context allocation failed");
+    }
+    *out = c;
+    return SB_OK;
+}
+
+int sb_destroy(sb_ctx *c) {
+    if (!c) return SB_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs})
+        if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : c->stage)
+        if (b.p) (void)hipFree(b.p);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->ticket) (void)hipFree(c->ticket);
+    if (c->stats) (void)hipFree(c->stats);
+    if (c->counters) (void)hipFree(c->counters);
+    delete c;
+    return SB_OK;
+}
+
+int sb_synchronize(sb_ctx *c) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SB_OK;
+}
+
+int sb_set_search_radius_hint(sb_ctx *c, int radius) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (radius < 1) return fail(c, SB_ERR_ARG, "radius must be >= 1");
+    c->radius_hint = radius;
+    return SB_OK;
+}
+
+int sb_last_counters(sb_ctx *c, long long counters[4]) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!counters) return fail(c, SB_ERR_ARG, "null pointer");
+    if (!c->have_last) return fail(c, SB_ERR_ARG, "no diag call yet");
+    HIPCHK(c, hipDeviceSynchronize());
+    const Geo &g = c->last_g;
+    std::vector<uint64_t> bits((size_t)g.nyh * g.nw);
+    std::vector<int> tiles((size_t)c->last_tiles);
+    int cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(bits.data(), c->bandbits.p, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tiles.data(), c->tiles.p, tiles.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cnt, c->counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    long long nb = 0;
+    for (uint64_t w : bits) nb += __builtin_popcountll(w);
+    int mx = 0;
+    for (int t : tiles) mx = t > mx ? t : mx;
+    counters[0] = nb; counters[1] = cnt[0]; counters[2] = cnt[1]; counters[3] = mx;
+    return SB_OK;
+}
+
+#define SB_DEFINE(T, SFX)                                                                                          \
+    int sb_seabreeze_diag_##SFX(sb_ctx *c, T dt, int tn, int nx, int ny, int nz, int halo, int bnd, const T *p,     \
+                                const T *u, const T *v, const T *theta, const T *mask, const T *z, const T *sigma,  \
+                                T *ws, T *wd, T *thc, T *sb_con, const sb_tunables *tun) {                          \
+        return seabreeze_diag_host<T>(c, dt, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, z, sigma, ws, wd,     \
+                                      thc, sb_con, tun);                                                            \
+    }                                                                                                              \
+    int sb_seabreeze_diag_##SFX##_dev(sb_ctx *c, T dt, int tn, int nx, int ny, int nz, int halo, int bnd,           \
+                                      const T *p, const T *u, const T *v, const T *theta, const T *mask,            \
+                                      const T *z, const T *sigma, T *ws, T *wd, T *thc, T *sb_con,                  \
+                                      const sb_tunables *tun, void *stream) {                                       \
+        return seabreeze_diag_dev<T>(c, dt, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, z, sigma, ws, wd, thc, \
+                                     sb_con, tun, stream);                                                          \
+    }                                                                                                              \
+    int sb_diag_##SFX(sb_ctx *c, int tn, const T *p, const T *z, const T *sd, const T *theta, const T *v,           \
+                      const T *u, const T *cdist, T *ws, T *wd, T *thc, T a0, T a1, T a2, T a3, T a4, T a5, T a6,   \
+                      T a7, int nps, int nlons, int nlats, T *output) {                                             \
+        return diag_host<T>(c, tn, p, z, sd, theta, v, u, cdist, ws, wd, thc, a0, a1, a2, a3, a4, a5, a6, a7, nps,  \
+                            nlons, nlats, output);                                                                  \
+    }                                                                                                              \
+    int sb_diag_##SFX##_dev(sb_ctx *c, int tn, const T *p, const T *z, const T *sd, const T *theta, const T *v,     \
+                            const T *u, const T *cdist, T *ws, T *wd, T *thc, T a0, T a1, T a2, T a3, T a4, T a5,   \
+                            T a6, T a7, int nps, int nlons, int nlats, T *output, void *stream) {                   \
+        return diag_dev<T>(c, tn, p, z, sd, theta, v, u, cdist, ws, wd, thc, a0, a1, a2, a3, a4, a5, a6, a7, nps,   \
+                           nlons, nlats, output, stream);                                                           \
+    }                                                                                                              \
+    int sb_sigmoid_##SFX(sb_ctx *c, int nx, int ny, const T *ary, T *sm) {                                          \
+        return sigmoid_host<T>(c, nx, ny, ary, sm);                                                                 \
+    }                                                                                                              \
+    int sb_sigmoid_##SFX##_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {                      \
+        return sigmoid_dev<T>(c, nx, ny, ary, sm, stream);                                                          \
+    }                                                                                                              \
+    int sb_get_edges_##SFX(sb_ctx *c, int nx, int ny, const T *lsm, const T *ci, int rule, int bnd, T *coast) {     \
+        return get_edges_host<T>(c, nx, ny, lsm, ci, rule, bnd, coast);                                             \
+    }                                                                                                              \
+    int sb_get_edges_##SFX##_dev(sb_ctx *c, int nx, int ny, const T *lsm, const T *ci, int rule, int bnd,           \
+                                 T *coast, void *stream) {                                                          \
+        return get_edges_dev<T>(c, nx, ny, lsm, ci, rule, bnd, coast, stream);                                      \
+    }                                                                                                              \
+    int sb_get_dist_##SFX(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const T *lon, const T *lat,     \
+                          T maxdist, int kwin, T *cdist) {                                                          \
+        return get_dist_host<T>(c, nx, ny, coast, mask, lon, lat, maxdist, kwin, cdist);                            \
+    }                                                                                                              \
+    int sb_get_dist_##SFX##_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const T *lon,             \
+                                const T *lat, T maxdist, int kwin, T *cdist, void *stream) {                        \
+        return get_dist_dev<T>(c, nx, ny, coast, mask, lon, lat, maxdist, kwin, cdist, stream);                     \
+    }                                                                                                              \
+    int sb_dist_window_##SFX(int nx, int ny, const T *lon, const T *lat, T maxdist, int *k) {                       \
+        return dist_window<T>(nx, ny, lon, lat, maxdist, k);                                                        \
+    }
+
+SB_DEFINE(double, f64)
+SB_DEFINE(float, f32)
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+"""ctypes binding of libseabreeze_hip.so (include/seabreeze_hip.h).
+
+This is plumbing only: every numerical result comes from the HIP kernels behind
+the C ABI.  There is no CPU fallback -- a missing library or a missing gfx950
+device raises.
+
+Arrays: C-contiguous numpy with reversed shape == Fortran (lon, lat[, lev]);
+see seabreeze_param_amd/synth.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseabreeze_hip.so")
+
+SB_BND_WRAPPER, SB_BND_GLOBAL, SB_BND_HALO = 0, 1, 2
+
+_SFX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
+_CT = {np.dtype(np.float32): C.c_float, np.dtype(np.float64): C.c_double}
+
+
+class SeabreezeHipError(RuntimeError):
+    pass
+
+
+class Tunables(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "target_plev_pa", "thresh_wind", "thresh_winddir", "thresh_windch",
+        "thresh_thc", "target_time_s", "maxdist_km")]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the product library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeabreezeHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sb_last_error.restype = C.c_char_p
+        _lib.sb_last_error.argtypes = [C.c_void_p]
+        _lib.sb_version.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a))       # raw device address
+
+
+def _host(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+class Context:
+    """One HIP device + stream + workspace (sb_ctx)."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.sb_create(C.byref(h), C.c_int(device))
+        if rc != 0:
+            raise SeabreezeHipError(f"sb_create failed ({rc}): {self.lib.sb_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise SeabreezeHipError(f"{what} failed ({rc}): {self.lib.sb_last_error(self.h).decode()}")
+
+    def synchronize(self):
+        self._chk(self.lib.sb_synchronize(self.h), "sb_synchronize")
+
+    def set_search_radius_hint(self, r: int):
+        self._chk(self.lib.sb_set_search_radius_hint(self.h, C.c_int(r)), "sb_set_search_radius_hint")
+
+    def last_counters(self):
+        arr = (C.c_longlong * 4)()
+        self._chk(self.lib.sb_last_counters(self.h, arr), "sb_last_counters")
+        return dict(band_cells=arr[0], global_path_cells=arr[1], one_class_cells=arr[2], max_radius=arr[3])
+
+    # ------------------------------------------------------------------ host-pointer API
+    def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
+                       halo=0, bnd=SB_BND_GLOBAL, tunables: Tunables | None = None):
+        """generic/sea_breeze_diag.f90:55 semantics; ws, wd, thc, sb_con updated in place."""
+        dt = np.dtype(ws.dtype)
+        sfx, ct = _SFX[dt], _CT[dt]
+        p = _host(p, dt); u = _host(u, dt); v = _host(v, dt)
+        theta = _host(theta, dt); mask = _host(mask, dt); z = _host(z, dt); sigma = _host(sigma, dt)
+        nz, ny, nx = p.shape
+        for a in (theta, mask, z, sigma):
+            if a.shape != (ny + 2 * halo, nx + 2 * halo):
+                raise ValueError(f"2-D input shape {a.shape} != {(ny + 2 * halo, nx + 2 * halo)}")
+        for a in (ws, wd, thc, sb_con):
+            if a.shape != (ny, nx) or a.dtype != dt or not a.flags.c_contiguous:
+                raise ValueError("state arrays must be C-contiguous (ny, nx) of the working dtype")
+        fn = getattr(self.lib, f"sb_seabreeze_diag_{sfx}")
+        rc = fn(self.h, ct(timestep), C.c_int(tn), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo),
+                C.c_int(bnd), _p(p), _p(u), _p(v), _p(theta), _p(mask), _p(z), _p(sigma),
+                _p(ws), _p(wd), _p(thc), _p(sb_con), C.byref(tunables) if tunables is not None else None)
+        self._chk(rc, "sb_seabreeze_diag")
+        return sb_con
+
+    def diag(self, tn, p, z, std, theta, v, u, cdist, ws, wd, thc, output=None,
+             target_plev=700.0, thresh_wind=11.0, thresh_winddir=90.0, thresh_windch=5.0,
+             thresh_thc=0.75, target_time=6.0, maxdist=180.0, timestep=24.0):
+        """seabreeze_diag_python.f90:49 semantics; ws, wd, thc updated in place; returns output(4, ny, nx)."""
+        dt = np.dtype(ws.dtype)
+        sfx, ct = _SFX[dt], _CT[dt]
+        p = _host(p, dt); z = _host(z, dt); std = _host(std, dt); theta = _host(theta, dt)
+        v = _host(v, dt); u = _host(u, dt); cdist = _host(cdist, dt)
+        nps = p.shape[0]
+        ny, nx = z.shape
+        if u.shape != (nps, ny, nx) or v.shape != (nps, ny, nx):
+            raise ValueError("u, v must be (nps, ny, nx)")
+        if output is None:
+            output = np.zeros((4, ny, nx), dtype=dt)
+        fn = getattr(self.lib, f"sb_diag_{sfx}")
+        rc = fn(self.h, C.c_int(tn), _p(p), _p(z), _p(std), _p(theta), _p(v), _p(u), _p(cdist),
+                _p(ws), _p(wd), _p(thc), ct(target_plev), ct(thresh_wind), ct(thresh_winddir),
+                ct(thresh_windch), ct(thresh_thc), ct(target_time), ct(maxdist), ct(timestep),
+                C.c_int(nps), C.c_int(nx), C.c_int(ny), _p(output))
+        self._chk(rc, "sb_diag")
+        return output
+
+    def sigmoid(self, ary):
+        ary = np.ascontiguousarray(ary)
+        dt = np.dtype(ary.dtype)
+        ny, nx = ary.shape
+        sm = np.empty_like(ary)
+        rc = getattr(self.lib, f"sb_sigmoid_{_SFX[dt]}")(self.h, C.c_int(nx), C.c_int(ny), _p(ary), _p(sm))
+        self._chk(rc, "sb_sigmoid")
+        return sm
+
+    def get_edges(self, lsm, ci, rule=0, bnd=SB_BND_WRAPPER):
+        lsm = np.ascontiguousarray(lsm)
+        dt = np.dtype(lsm.dtype)
+        ci = _host(ci, dt)
+        ny, nx = lsm.shape
+        coast = np.empty_like(lsm)
+        rc = getattr(self.lib, f"sb_get_edges_{_SFX[dt]}")(self.h, C.c_int(nx), C.c_int(ny), _p(lsm), _p(ci),
+                                                          C.c_int(rule), C.c_int(bnd), _p(coast))
+        self._chk(rc, "sb_get_edges")
+        return coast
+
+    def get_dist(self, coast, mask, lon, lat, maxdist=180.0, kwin=-1):
+        coast = np.ascontiguousarray(coast)
+        dt = np.dtype(coast.dtype)
+        mask = _host(mask, dt); lon = _host(lon, dt); lat = _host(lat, dt)
+        ny, nx = coast.shape
+        cdist = np.empty_like(coast)
+        rc = getattr(self.lib, f"sb_get_dist_{_SFX[dt]}")(self.h, C.c_int(nx), C.c_int(ny), _p(coast), _p(mask),
+                                                         _p(lon), _p(lat), _CT[dt](maxdist), C.c_int(kwin),
+                                                         _p(cdist))
+        self._chk(rc, "sb_get_dist")
+        return cdist
+
+    # ------------------------------------------------------------------ device-pointer API
+    def seabreeze_diag_dev(self, dtype, timestep, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, z, sigma,
+                           ws, wd, thc, sb_con, stream=None, tunables: Tunables | None = None):
+        """All array arguments are raw device addresses (ints); enqueues without synchronising."""
+        dt = np.dtype(dtype)
+        fn = getattr(self.lib, f"sb_seabreeze_diag_{_SFX[dt]}_dev")
+        rc = fn(self.h, _CT[dt](timestep), C.c_int(tn), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo),
+                C.c_int(bnd), _p(p), _p(u), _p(v), _p(theta), _p(mask), _p(z), _p(sigma), _p(ws), _p(wd),
+                _p(thc), _p(sb_con), C.byref(tunables) if tunables is not None else None,
+                C.c_void_p(stream) if stream else None)
+        self._chk(rc, "sb_seabreeze_diag_dev")
+
+
+def dist_window(lon, lat, maxdist=180.0) -> int:
+    lib = load_library()
+    lon = np.ascontiguousarray(lon)
+    dt = np.dtype(lon.dtype)
+    lat = _host(lat, dt)
+    k = C.c_int(0)
+    rc = getattr(lib, f"sb_dist_window_{_SFX[dt]}")(C.c_int(lon.size), C.c_int(lat.size), _p(lon), _p(lat),
+                                                   _CT[dt](maxdist), C.byref(k))
+    if rc != 0:
+        raise SeabreezeHipError(f"sb_dist_window failed ({rc}): {lib.sb_last_error(None).decode()}")
+    return k.value
+
+
+def get_threads() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    lib.sb_get_threads(C.byref(n))
+    return n.value
