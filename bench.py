@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- grid-points/s of one seabreeze_diag call (BASELINE.json metric).
+
+A "step" is one full seabreeze_diag call (generic/sea_breeze_diag.f90:55 semantics:
+sigmoid statistics, t0, window contrast, per-column level search, thresholds, state
+update) over the whole grid, inputs already resident in HBM.  Default workload:
+configs[2] of BASELINE.json, the configuration the metric is quoted on -- N1280
+(2560x1920) fp64 with nz=56 levels -- which fits one MI355X (about 16 GB).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N>1 splits the grid into N latitude bands (strong scaling): per step every rank
+all-gathers its sigma moments and swaps theta halo rows with its band neighbours over
+RCCL (the reference's swap_bounds stub, generic/halo_exchange_mod.f90:12-17).
+
+Prints ONE JSON line on rank 0 with the `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from seabreeze_param_amd import hip, synth  # noqa: E402
+from seabreeze_param_amd.bands import BandRunner, split_rows  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(n, n_band, nz, s=8):
+    """B = s*[5N + (nz+7)*N_c], split per kernel."""
+    return {
+        "k_stats": s * n,                                  # read sigma
+        "k_prep": s * (3 * n + (n - n_band)),              # read theta,z,mask; write sb_con outside the band
+        "k_thc": s * n_band,                               # write thc
+        "k_wind": s * (nz + 6) * n_band,                   # p column, u, v, ws, wd in; sb_con, ws, wd out
+        "total": s * (5 * n + (nz + 7) * n_band),
+    }
+
+
+def host_cores() -> int:
+    """Cores this process may really use: affinity, capped by the cgroup CPU quota and by
+    the 16-core share a one-GPU box grants."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0):
+    """Time the CPU oracle (our Fortran restatement of the reference, `kind: port`) on
+    this box's host cores: serial and all-core OpenMP, bounded by budget_s each."""
+    from oracle.pyoracle import Oracle        # checker / baseline only
+    ny, nx = st.ny, st.nx
+    out = {}
+    ncores = host_cores()
+    for name, omp in (("serial", False), ("omp", True)):
+        if omp:
+            os.environ["OMP_NUM_THREADS"] = str(ncores)
+        orc = Oracle(8, omp=omp)
+        state = [np.zeros((ny, nx)) for _ in range(4)]
+        times = []
+        t_all = time.perf_counter()
+        tn = 1
+        while True:
+            t0 = time.perf_counter()
+            orc.seabreeze_diag(1440.0, tn, p, u, v, theta, cdist, st.z, st.sigma, *state, halo=0, bnd=1, omp=omp)
+            times.append(time.perf_counter() - t0)
+            tn += 1
+            if time.perf_counter() - t_all > budget_s or len(times) >= 12:
+                break
+        # first call pays page faults; use the median of the rest when there is a rest
+        med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+        out[name] = dict(s_per_call=med, calls=len(times))
+    return out, ncores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=2560)
+    ap.add_argument("--ny", type=int, default=1920)
+    ap.add_argument("--nz", type=int, default=56)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline per variant")
+    ap.add_argument("--profile-passes", type=int, default=1,
+                    help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nx, ny, nz = args.nx, args.ny, args.nz
+    dt = np.float64
+    K, W = args.steps, args.warmup
+
+    # ---- synthetic inputs (host, deterministic), shared by GPU and CPU baseline --------
+    t_gen = time.perf_counter()
+    st = synth.static_fields(nx, ny, dt)
+    ctx = hip.Context(local_rank)
+    coast = ctx.get_edges(st.landfrac, st.icefrac)                    # HIP (product) setup chain
+    cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
+    kwin = hip.dist_window(st.lon, st.lat)
+    band = np.abs(cdist) <= 180.0
+    n_band_total = int(band.sum())
+    r0, r1 = split_rows(ny, world)[rank]
+    p_full = synth.pressure_3d(st, nz, dt)
+    theta_a = synth.theta_step(st, 1, dt)
+    theta_b = synth.theta_step(st, 2, dt)
+    u_full, v_full = synth.wind_step(st, nz, 1, dt)
+    gen_s = time.perf_counter() - t_gen
+
+    runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1)
+    runner.upload_static(st.z, st.sigma, cdist)
+    # two input sets at different addresses: B swaps u and v (distinct synthetic winds) and
+    # uses the next step's theta, so no step re-reads the lines the previous one fetched
+    set_a = runner.upload_step_inputs(p_full, u_full, v_full, theta_a)
+    set_b = runner.upload_step_inputs(p_full, v_full, u_full, theta_b)
+    sets = (set_a, set_b)
+    timestep = 1440.0    # s; target_time branch fires every 15th step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    tn = 1
+    for _ in range(W):
+        runner.step(timestep, tn, sets[tn % 2]); tn += 1
+    torch.cuda.synchronize(); barrier()
+
+    events_inside = args.profile_passes == 0
+    if events_inside:
+        ctx.profile_begin(K)
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        runner.step(timestep, tn, sets[tn % 2]); tn += 1
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel HIP-event timing (same stream, same inputs, live in this run) -------
+    if not events_inside:
+        ctx.profile_begin(K * args.profile_passes)
+        for _ in range(K * args.profile_passes):
+            runner.step(timestep, tn, sets[tn % 2]); tn += 1
+    kern_ms, ncalls = ctx.profile_end()
+    counters = ctx.last_counters()
+
+    ms_per_step = elapsed / K * 1e3
+    value = nx * ny / (elapsed / K)
+
+    n_local = nx * (r1 - r0)
+    n_band_local = int(band[r0:r1].sum())
+    ab = algorithmic_bytes(n_local, n_band_local, nz)
+    dom = max(("k_stats", "k_prep", "k_thc", "k_wind"), key=lambda k: kern_ms[k])
+    dom_gbs = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+    call_gbs = ab["total"] / (elapsed / K) / 1e9
+
+    result = {
+        "metric": "grid-points/sec for sea_breeze_diag on N2560x1920 global grid; achieved HBM GB/s",
+        "value": value,
+        "unit": "grid-points/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"seabreeze_diag generic flavour, N{nx // 2} ({nx}x{ny}) global grid, nz={nz}, fp64 "
+                        f"(BASELINE.json configs[2])",
+            "nx": nx, "ny": ny, "nz": nz,
+            "band_fraction": n_band_total / (nx * ny),
+            "search_halo": kwin + 1,
+            "parallelism": f"latband{world}",
+            "input_gen_s": round(gen_s, 1),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": dom_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": dom_gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": ab[dom],
+            "kernel_ms": {k: round(vv, 5) for k, vv in kern_ms.items()},
+            "kernel_algorithmic_bytes": {k: ab[k] for k in ("k_stats", "k_prep", "k_thc", "k_wind")},
+            "event_calls": ncalls,
+            "whole_call": {"algorithmic_bytes": ab["total"], "achieved": call_gbs, "frac": call_gbs / HBM_PEAK_GBS},
+            "rank0_counters": counters,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ncores = cpu_baseline(st, cdist, p_full, u_full, v_full, theta_a, nz, args.cpu_budget)
+        result["cpu_baseline"] = {
+            "value": nx * ny / cb["omp"]["s_per_call"],
+            "unit": "grid-points/s",
+            "cores": ncores,
+            "kind": "port",
+            "sample": f"{cb['omp']['calls']} full calls of the same {nx}x{ny}x{nz} workload "
+                      f"(median of calls 2..n), oracle/sb_oracle.f90 amdflang -O2 -fopenmp",
+            "serial": {"value": nx * ny / cb["serial"]["s_per_call"], "cores": 1, "calls": cb["serial"]["calls"]},
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,12 @@ int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
    Synchronises the context's stream.                                                */
 int  sb_last_counters(sb_ctx *ctx, long long counters[4]);
 int  sb_synchronize(sb_ctx *ctx);
+/* Per-kernel timing with HIP events on the stream the kernels run on.  Between
+   sb_profile_begin and sb_profile_end the first `max_calls` diag calls record five
+   events around their four kernels; sb_profile_end synchronises and returns the
+   average duration in ms of [0] k_stats [1] k_prep [2] k_thc [3] k_wind.            */
+int  sb_profile_begin(sb_ctx *ctx, int max_calls);
+int  sb_profile_end(sb_ctx *ctx, double avg_ms[4], int *ncalls);
 
 /* -------------------------------------------------------------------------------- */
 /* seabreeze_diag -- host-model flavour                                              */
@@ -178,6 +184,18 @@ int sb_sigmoid_f64(sb_ctx *ctx, int nlons, int nlats, const double *ary, double 
 int sb_sigmoid_f32(sb_ctx *ctx, int nlons, int nlats, const float *ary, float *sm);
 int sb_sigmoid_f64_dev(sb_ctx *ctx, int nlons, int nlats, const double *ary, double *sm, void *stream);
 int sb_sigmoid_f32_dev(sb_ctx *ctx, int nlons, int nlats, const float *ary, float *sm, void *stream);
+
+/* Latitude-band decomposition: the sigmoid needs GLOBAL statistics of sigma
+   (ref: generic/sea_breeze_diag.f90:466-479).  Each band computes its own moments
+   {count, mean, sum of squared deviations, min, max} (5 doubles, device memory), the
+   host model all-gathers them (RCCL), and every following diag call on this context
+   merges the gathered array (rank order, bit-identical on all ranks) instead of
+   scanning its local sigma.  sb_use_gathered_moments(ctx, NULL, 0) switches back.     */
+int sb_sigma_moments_f64_dev(sb_ctx *ctx, int nx, int ny, int halo, const double *sigma,
+                             double *moments5, void *stream);
+int sb_sigma_moments_f32_dev(sb_ctx *ctx, int nx, int ny, int halo, const float *sigma,
+                             double *moments5, void *stream);
+int sb_use_gathered_moments(sb_ctx *ctx, const double *gathered_dev, int nparts);
 
 /* -------------------------------------------------------------------------------- */
 /* get_edges -- coastline by binary 3x3 Sobel                                        */

@@ -1,0 +1,127 @@
+"""Latitude-band decomposition of the global grid across the GPUs of one node.
+
+The reference's only communication point is `swap_bounds(field, halo_size)`, an empty
+stub (generic/halo_exchange_mod.f90:12-17) that a host model replaces with its own halo
+exchange (UM: UM/vn10.7/sea_breeze_diag.F90:408-410).  Here each rank owns a contiguous
+band of latitude rows with full longitude circles, so
+
+* E-W periodicity is a local copy into the ghost columns,
+* N-S ghost rows come from the band neighbours by point-to-point send/recv over
+  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
+  tests), poles replicate their edge row (the lat clamp of the global-grid rule),
+* the sigmoid's global statistics are an all-gather of 5 doubles per rank, merged in
+  rank order on the device (sb_use_gathered_moments).
+
+`BandRunner` is torch plumbing around the C ABI: device memory, streams, collectives.
+The arithmetic is all in libseabreeze_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hip as _hip
+
+
+def split_rows(ny: int, world: int):
+    """Contiguous, near-equal latitude bands: [(r0, r1), ...] with r1 exclusive."""
+    base, rem = divmod(ny, world)
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < rem else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+def fill_ew_ghosts(loc, nx: int, h: int):
+    """Periodic longitude wrap into the ghost columns of a (rows, nx+2h) array (torch or numpy)."""
+    if h == 0:
+        return
+    loc[:, :h] = loc[:, nx:nx + h]
+    loc[:, nx + h:] = loc[:, h:2 * h]
+
+
+def exchange_ns(loc, nyl: int, h: int, rank: int, world: int, dist, torch):
+    """Fill the N-S ghost rows of a (nyl+2h, W) array from the band neighbours; pole-side
+    ghost rows replicate the edge row.  `dist` is torch.distributed (any backend)."""
+    if h == 0:
+        return
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, loc[h:2 * h], rank - 1))
+        ops.append(dist.P2POp(dist.irecv, loc[0:h], rank - 1))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, loc[nyl:nyl + h], rank + 1))
+        ops.append(dist.P2POp(dist.irecv, loc[nyl + h:nyl + 2 * h], rank + 1))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    for r in reqs:
+        r.wait()
+    if rank == 0:
+        loc[0:h] = loc[h:h + 1]
+    if rank == world - 1:
+        loc[nyl + h:] = loc[nyl + h - 1:nyl + h]
+
+
+class BandRunner:
+    """Owns one rank's device-resident fields and runs seabreeze_diag steps on them."""
+
+    def __init__(self, ctx: _hip.Context, torch, dist, rank: int, world: int, nx: int, ny: int, nz: int,
+                 halo: int, dtype=np.float64):
+        self.ctx, self.torch, self.dist = ctx, torch, dist
+        self.rank, self.world = rank, world
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.dtype = np.dtype(dtype)
+        self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        self.r0, self.r1 = split_rows(ny, world)[rank]
+        self.nyl = self.r1 - self.r0
+        self.h = halo if world > 1 else 0
+        self.bnd = _hip.SB_BND_HALO if world > 1 else _hip.SB_BND_GLOBAL
+        if world > 1 and self.nyl < self.h:
+            raise ValueError(f"band of {self.nyl} rows is thinner than the halo {self.h}")
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        z = lambda: torch.zeros((self.nyl, nx), dtype=self.tdtype, device=self.dev)
+        self.ws, self.wd, self.thc, self.sb_con = z(), z(), z(), z()
+        if world > 1:
+            self.mom = torch.zeros(5, dtype=torch.float64, device=self.dev)
+            self.gath = torch.zeros(5 * world, dtype=torch.float64, device=self.dev)
+            ctx.use_gathered_moments(self.gath.data_ptr(), world)
+        ctx.set_search_radius_hint(halo)
+
+    # -- uploads -----------------------------------------------------------------------
+    def _halo_field(self, full2d):
+        """Interior rows of this band inside a ghost-cell frame (ghosts zero until exchanged)."""
+        t, h = self.torch, self.h
+        loc = t.zeros((self.nyl + 2 * h, self.nx + 2 * h), dtype=self.tdtype, device=self.dev)
+        src = t.from_numpy(np.ascontiguousarray(full2d[self.r0:self.r1])).to(self.dev)
+        loc[h:h + self.nyl, h:h + self.nx] = src
+        return loc
+
+    def _fill_ghosts(self, loc):
+        if self.world > 1:
+            exchange_ns(loc, self.nyl, self.h, self.rank, self.world, self.dist, self.torch)
+            fill_ew_ghosts(loc, self.nx, self.h)
+
+    def upload_static(self, z, sigma, mask):
+        self.z, self.sigma, self.mask = (self._halo_field(a) for a in (z, sigma, mask))
+        for a in (self.z, self.sigma, self.mask):      # static fields: ghosts exchanged once
+            self._fill_ghosts(a)
+
+    def upload_step_inputs(self, p, u, v, theta):
+        t = self.torch
+        band3 = lambda a: t.from_numpy(np.ascontiguousarray(a[:, self.r0:self.r1])).to(self.dev)
+        return dict(p=band3(p), u=band3(u), v=band3(v), theta=self._halo_field(theta))
+
+    # -- one model step -------------------------------------------------------------------
+    def step(self, timestep: float, tn: int, s):
+        t = self.torch
+        stream = t.cuda.current_stream().cuda_stream
+        if self.world > 1:
+            self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
+                                       self.mom.data_ptr(), stream)
+            self.dist.all_gather_into_tensor(self.gath, self.mom)
+            self._fill_ghosts(s["theta"])               # theta changes every step
+        self.ctx.seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h, self.bnd,
+                                    s["p"].data_ptr(), s["u"].data_ptr(), s["v"].data_ptr(),
+                                    s["theta"].data_ptr(), self.mask.data_ptr(), self.z.data_ptr(),
+                                    self.sigma.data_ptr(), self.ws.data_ptr(), self.wd.data_ptr(),
+                                    self.thc.data_ptr(), self.sb_con.data_ptr(), stream)

@@ -28,8 +28,9 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
+    int ncu = 256;              // compute units of the device
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps;
     Moments *partials = nullptr;
     unsigned int *ticket = nullptr;
     void *stats = nullptr;      // 4 x double
@@ -40,6 +41,11 @@ struct sb_ctx {
     Geo last_g{};
     int last_tiles = 0;
     bool have_last = false;
+    // optional per-kernel HIP-event timing (sb_profile_begin / sb_profile_end)
+    const Moments *gathered = nullptr;   // device array of per-band sigma moments (multi-GPU), or null
+    int ngathered = 0;
+    std::vector<hipEvent_t> prof_ev;
+    int prof_calls = 0, prof_max = 0;
 };
 
 namespace {
@@ -98,17 +104,28 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st) {
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
-    int tx, ty;
-    sb_thc_tiles<T>(g.nx, g.rows, H, tx, ty);
-    if ((rc = ensure(c, c->tiles, (size_t)tx * ty * sizeof(int)))) return rc;
+    const int tyrows = sb_thc_tile_rows(H);
+    const int tx = (g.nx + 63) / 64, ty = (g.rows + tyrows - 1) / tyrows;
+    // per-tile flags followed by the two slow-path counters: one memset clears both
+    if ((rc = ensure(c, c->tiles, ((size_t)tx * ty + 2) * sizeof(int)))) return rc;
+    job.thc_ty = tyrows; job.thc_ntx = tx; job.thc_nty = ty;
     job.t0 = (T *)c->t0.p;
     job.bandbits = (uint64_t *)c->bandbits.p;
     job.clsbits = (uint64_t *)c->clsbits.p;
     job.stats = (const T *)c->stats;
     job.tile_nnmax = (int *)c->tiles.p;
-    job.counters = c->counters;
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, 2 * sizeof(int), st));
-    HIPCHK(c, sb_launch_diag<T>(job, H, c->partials, c->ticket, (T *)c->stats, st));
+    job.counters = (int *)c->tiles.p + (size_t)tx * ty;
+    job.stamps = nullptr;
+#ifdef SB_STAMPS
+    if ((rc = ensure(c, c->stamps, (size_t)tx * ty * 8 * sizeof(long long)))) return rc;
+    job.stamps = (long long *)c->stamps.p;
+    HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, (size_t)tx * ty * 8 * sizeof(long long), st));
+#endif
+    HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, ((size_t)tx * ty + 2) * sizeof(int), st));
+    hipEvent_t *ev = nullptr;
+    if (c->prof_calls < c->prof_max) ev = &c->prof_ev[(size_t)5 * c->prof_calls++];
+    HIPCHK(c, sb_launch_diag<T>(job, H, c->partials, c->ticket, (T *)c->stats, st, ev, c->gathered, c->ngathered,
+                                c->ncu));
     c->last_g = g;
     c->last_tiles = tx * ty;
     c->have_last = true;
@@ -266,7 +283,7 @@ int sigmoid_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, c->ticket, (T *)c->stats, st));
+    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, c->ticket, (T *)c->stats, nullptr, st));
     HIPCHK(c, sb_launch_sigmoid_apply<T>(ary, sm, (size_t)nx * ny, (const T *)c->stats, st));
     return SB_OK;
 }
@@ -283,6 +300,17 @@ int sigmoid_host(sb_ctx *c, int nx, int ny, const T *ary, T *sm) {
     if (rc) return rc;
     s.back(sm, ds, n);
     return s.finish();
+}
+
+template <typename T>
+int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, double *moments5, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (nx < 1 || ny < 1 || halo < 0 || !sigma || !moments5) return fail(c, SB_ERR_ARG, "bad sigma_moments arguments");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const int nxh = nx + 2 * halo;
+    HIPCHK(c, sb_launch_stats<T>(sigma, nx, ny, nxh, (size_t)halo * nxh + halo, c->partials, c->ticket,
+                                 (T *)c->stats, (Moments *)moments5, st));
+    return SB_OK;
 }
 
 template <typename T>
@@ -426,6 +454,7 @@ int sb_create(sb_ctx **out, int device) {
                     std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     sb_ctx *c = new sb_ctx();
     c->device = device;
+    c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return hipfail(nullptr, e, "hipStreamCreate");
@@ -448,7 +477,8 @@ int sb_destroy(sb_ctx *c) {
     if (!c) return SB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs})
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);
@@ -466,6 +496,64 @@ int sb_synchronize(sb_ctx *c) {
     return SB_OK;
 }
 
+#ifdef SB_STAMPS
+// diagnostic build only: copy the per-tile clock stamps of the last diag call to the host
+int sb_debug_stamps(sb_ctx *c, long long *host, int ntiles_max, int *ntiles) {
+    if (!c || !host || !ntiles || !c->have_last) return SB_ERR_ARG;
+    HIPCHK(c, hipDeviceSynchronize());
+    const int n = c->last_tiles < ntiles_max ? c->last_tiles : ntiles_max;
+    HIPCHK(c, hipMemcpy(host, c->stamps.p, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    *ntiles = n;
+    return SB_OK;
+}
+#endif
+
+int sb_sigma_moments_f64_dev(sb_ctx *c, int nx, int ny, int halo, const double *sigma, double *m5, void *stream) {
+    return sigma_moments_dev<double>(c, nx, ny, halo, sigma, m5, stream);
+}
+int sb_sigma_moments_f32_dev(sb_ctx *c, int nx, int ny, int halo, const float *sigma, double *m5, void *stream) {
+    return sigma_moments_dev<float>(c, nx, ny, halo, sigma, m5, stream);
+}
+
+int sb_use_gathered_moments(sb_ctx *c, const double *gathered, int nparts) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (gathered && nparts < 1) return fail(c, SB_ERR_ARG, "nparts must be >= 1");
+    static_assert(sizeof(Moments) == 5 * sizeof(double), "Moments is 5 doubles");
+    c->gathered = (const Moments *)gathered;
+    c->ngathered = gathered ? nparts : 0;
+    return SB_OK;
+}
+
+int sb_profile_begin(sb_ctx *c, int max_calls) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (max_calls < 1 || max_calls > 100000) return fail(c, SB_ERR_ARG, "max_calls out of range");
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    c->prof_ev.assign((size_t)5 * max_calls, nullptr);
+    for (hipEvent_t &e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
+    c->prof_calls = 0;
+    c->prof_max = max_calls;
+    return SB_OK;
+}
+
+int sb_profile_end(sb_ctx *c, double avg_ms[4], int *ncalls) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
+    HIPCHK(c, hipDeviceSynchronize());
+    double sum[4] = {0, 0, 0, 0};
+    for (int i = 0; i < c->prof_calls; ++i)
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->prof_ev[(size_t)5 * i + k], c->prof_ev[(size_t)5 * i + k + 1]));
+            sum[k] += ms;
+        }
+    *ncalls = c->prof_calls;
+    for (int k = 0; k < 4; ++k) avg_ms[k] = c->prof_calls ? sum[k] / c->prof_calls : 0.0;
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    c->prof_ev.clear();
+    c->prof_calls = c->prof_max = 0;
+    return SB_OK;
+}
+
 int sb_set_search_radius_hint(sb_ctx *c, int radius) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (radius < 1) return fail(c, SB_ERR_ARG, "radius must be >= 1");
@@ -480,11 +568,13 @@ int sb_last_counters(sb_ctx *c, long long counters[4]) {
     HIPCHK(c, hipDeviceSynchronize());
     const Geo &g = c->last_g;
     std::vector<uint64_t> bits((size_t)g.nyh * g.nw);
-    std::vector<int> tiles((size_t)c->last_tiles);
+    std::vector<int> tiles((size_t)c->last_tiles + 2);
     int cnt[2] = {0, 0};
     HIPCHK(c, hipMemcpy(bits.data(), c->bandbits.p, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(tiles.data(), c->tiles.p, tiles.size() * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(cnt, c->counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    cnt[0] = tiles[(size_t)c->last_tiles];
+    cnt[1] = tiles[(size_t)c->last_tiles + 1];
+    tiles.resize((size_t)c->last_tiles);
     long long nb = 0;
     for (uint64_t w : bits) nb += __builtin_popcountll(w);
     int mx = 0;

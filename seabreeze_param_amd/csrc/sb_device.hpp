@@ -92,8 +92,10 @@ struct DiagJob {
     uint64_t *bandbits;             // nyh * nw words: interior cells with |mask| <= maxdist
     uint64_t *clsbits;              // nyh * nw words: mask >= 0 ("land side")
     const T *stats;                 // [0]=std  [1]=r  (sigmoid scalars)
-    int *tile_nnmax;                // per thc-tile largest radius used
+    int thc_ty, thc_ntx, thc_nty;   // k_thc tile rows and tile-grid shape (tiles are 64 x thc_ty cells)
+    int *tile_nnmax;                // per thc tile: 0 = no band cell; k_prep raises 1, k_thc leaves the largest radius
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
+    long long *stamps;              // diagnostic build (-DSB_STAMPS) only: 8 clock stamps per thc tile
 };
 
 __device__ __forceinline__ int sb_bit(const uint64_t *bits, int nw, int X, int Y) {

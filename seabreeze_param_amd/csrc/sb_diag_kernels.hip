@@ -19,7 +19,7 @@
 // ------------------------------------------------------------------------------------
 // k_stats
 // ------------------------------------------------------------------------------------
-#define STATS_NT 256
+#define STATS_NT 1024
 
 __device__ __forceinline__ Moments wave_merge(Moments m) {
 #pragma unroll
@@ -35,53 +35,86 @@ __device__ __forceinline__ Moments wave_merge(Moments m) {
     return m;
 }
 
+// merge across the waves of a workgroup; the result is valid in thread 0
+__device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
+    m = wave_merge(m);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();                             // wpart may still be read from a previous use
+    if (lane == 0) wpart[wv] = m;
+    __syncthreads();
+    Moments r = moments_empty();
+    if (threadIdx.x < SB_WAVE) {
+        if (threadIdx.x < STATS_NT / SB_WAVE) r = wpart[threadIdx.x];
+        r = wave_merge(r);
+    }
+    return r;
+}
+
+// std = 2/sqrt(var/N), r = (max-min)/4 in the working precision
+// ref: generic/sea_breeze_diag.f90:478-479 (N = nlons*nlats, the merged sample count)
+template <typename T>
+__device__ __forceinline__ void sigmoid_scalars(const Moments &m, T *__restrict__ stats) {
+    const T var = (T)m.m2;
+    const T cnt = (T)m.n;
+    stats[0] = T(2) / sqrt(var / cnt);
+    stats[1] = ((T)m.mx - (T)m.mn) / T(4);
+    stats[2] = (T)m.mean;
+    stats[3] = var;
+}
+
+// One workgroup per CU streams its share of sigma with 8 independent loads per thread in
+// flight.  Sums are taken about a common shift c (the first interior value), so the inner
+// loop is two adds and a multiply per element; the shifted sums become (n, mean, M2) once
+// per thread and are merged pairwise (Chan) from there on.  The last workgroup to take a
+// ticket merges the per-workgroup partials in index order, so the result does not depend
+// on arrival order.
 template <typename T>
 __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, int nx, int ny, int ld,
                                                     size_t off0, Moments *__restrict__ partials,
                                                     unsigned int *__restrict__ ticket,
-                                                    T *__restrict__ stats) {
-    // grid-stride over interior cells, 4 independent loads per thread per trip
-    const size_t n = (size_t)nx * ny;
-    const size_t stride = (size_t)gridDim.x * STATS_NT;
-    Moments acc = moments_empty();
-    for (size_t base = (size_t)blockIdx.x * STATS_NT + threadIdx.x; base < n; base += 4 * stride) {
-        double x[4];
-        int cnt = 0;
+                                                    T *__restrict__ stats, Moments *__restrict__ moments_out) {
+    const unsigned n = (unsigned)nx * (unsigned)ny;
+    const unsigned stride = gridDim.x * STATS_NT;
+    const bool flat = (ld == nx);
+    const double c = (double)ary[off0];
+    double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
+    int cnt = 0;
+    for (unsigned base = blockIdx.x * STATS_NT + threadIdx.x; base < n; base += 8 * stride) {
+        double x[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            size_t i = base + q * stride;
+        for (int q = 0; q < 8; ++q) {
+            const unsigned i = base + q * stride;
+            x[q] = c;
             if (i < n) {
-                size_t row = i / nx, col = i - row * nx;
-                x[cnt++] = (double)ary[off0 + row * ld + col];
+                const size_t idx = flat ? (size_t)i : (size_t)(i / (unsigned)nx) * ld + (i % (unsigned)nx);
+                x[q] = (double)ary[off0 + idx];
             }
         }
-        // exact two-pass moments of the (<=4) register values, then one merge
-        double s = 0.0;
-        for (int q = 0; q < cnt; ++q) s += x[q];
-        Moments b;
-        b.n = (double)cnt;
-        b.mean = s / (double)cnt;
-        b.m2 = 0.0;
-        b.mn = x[0];
-        b.mx = x[0];
-        for (int q = 0; q < cnt; ++q) {
-            double d = x[q] - b.mean;
-            b.m2 += d * d;
-            b.mn = x[q] < b.mn ? x[q] : b.mn;
-            b.mx = x[q] > b.mx ? x[q] : b.mx;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (base + q * stride < n) {
+                const double d = x[q] - c;
+                s1 += d;
+                s2 += d * d;
+                mn = x[q] < mn ? x[q] : mn;
+                mx = x[q] > mx ? x[q] : mx;
+                ++cnt;
+            }
         }
-        acc = moments_merge(acc, b);
+    }
+    Moments acc = moments_empty();
+    if (cnt > 0) {
+        acc.n = (double)cnt;
+        acc.mean = c + s1 / acc.n;
+        acc.m2 = s2 - s1 * s1 / acc.n;
+        acc.mn = mn;
+        acc.mx = mx;
     }
     __shared__ Moments wpart[STATS_NT / SB_WAVE];
     __shared__ bool is_last;
-    acc = wave_merge(acc);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wpart[wv] = acc;
-    __syncthreads();
+    acc = block_merge(acc, wpart);
     if (threadIdx.x == 0) {
-        Moments m = wpart[0];
-        for (int w = 1; w < STATS_NT / SB_WAVE; ++w) m = moments_merge(m, wpart[w]);
-        partials[blockIdx.x] = m;
+        partials[blockIdx.x] = acc;
         // publish: agent-scope release, drained, then the ticket
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -90,34 +123,41 @@ __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, i
     }
     __syncthreads();
     if (!is_last) return;
-    // last block to arrive: merge all partials in index order (deterministic tree)
-    if (wv == 0) {
+    // last workgroup to arrive: every thread fetches one partial, then a fixed merge tree
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        Moments m = moments_empty();
-        for (int b = lane; b < (int)gridDim.x; b += SB_WAVE) {
-            const Moments *pp = &partials[b];
-            Moments o;
-            o.n = __builtin_nontemporal_load(&pp->n);
-            o.mean = __builtin_nontemporal_load(&pp->mean);
-            o.m2 = __builtin_nontemporal_load(&pp->m2);
-            o.mn = __builtin_nontemporal_load(&pp->mn);
-            o.mx = __builtin_nontemporal_load(&pp->mx);
-            m = moments_merge(m, o);
-        }
-        m = wave_merge(m);
-        if (lane == 0) {
-            // std = 2/sqrt(var/N), r = (max-min)/4 in the working precision
-            // ref: generic/sea_breeze_diag.f90:478-479
-            const T var = (T)m.m2;
-            const T cnt = (T)(nx * ny);          // reference: default-integer product
-            stats[0] = T(2) / sqrt(var / cnt);
-            stats[1] = ((T)m.mx - (T)m.mn) / T(4);
-            stats[2] = (T)m.mean;
-            stats[3] = var;
-            *ticket = 0u;                        // re-arm for the next call on this stream
-        }
     }
+    __syncthreads();
+    Moments m = moments_empty();
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += STATS_NT) {
+        const Moments *pp = &partials[b];
+        Moments o;
+        o.n = __builtin_nontemporal_load(&pp->n);
+        o.mean = __builtin_nontemporal_load(&pp->mean);
+        o.m2 = __builtin_nontemporal_load(&pp->m2);
+        o.mn = __builtin_nontemporal_load(&pp->mn);
+        o.mx = __builtin_nontemporal_load(&pp->mx);
+        m = moments_merge(m, o);
+    }
+    m = block_merge(m, wpart);
+    if (threadIdx.x == 0) {
+        if (moments_out) *moments_out = m;       // band-local moments for the multi-GPU gather
+        else sigmoid_scalars<T>(m, stats);
+        *ticket = 0u;                            // re-arm for the next call on this stream
+    }
+}
+
+// Merge the moments gathered from every latitude band (one entry per rank) and derive the
+// sigmoid scalars; a single wave.  The merge order is rank order on every rank, so all
+// ranks hold bit-identical scalars.
+template <typename T>
+__global__ __launch_bounds__(SB_WAVE) void k_merge_moments(const Moments *__restrict__ parts, int nparts,
+                                                           T *__restrict__ stats) {
+    Moments m = moments_empty();
+    for (int b = threadIdx.x; b < nparts; b += SB_WAVE) m = moments_merge(m, parts[b]);
+    m = wave_merge(m);
+    if (threadIdx.x == 0) sigmoid_scalars<T>(m, stats);
 }
 
 // ------------------------------------------------------------------------------------
@@ -159,9 +199,19 @@ __global__ __launch_bounds__(256) void k_prep(DiagJob<T> job) {
     }
     const uint64_t wc = __ballot(cls);
     const uint64_t wb = __ballot(band);
+    // raise the flag of every thc tile this segment's band cells fall in (it straddles two
+    // tile columns when the ghost width is not a multiple of 64); plain stores of 1
+    const int tA = ((X & ~63) - g.h) >> 6;
+    const uint64_t mA = __ballot(band && (xi >> 6) == tA);
+    const uint64_t mB = __ballot(band && (xi >> 6) == tA + 1);
     if ((threadIdx.x & 63) == 0 && (X >> 6) < g.nw) {
         job.clsbits[(size_t)Y * g.nw + (X >> 6)] = wc;
         job.bandbits[(size_t)Y * g.nw + (X >> 6)] = wb;
+        if (wb) {
+            const int trow = (yi / job.thc_ty) * job.thc_ntx;
+            if (mA) job.tile_nnmax[trow + tA] = 1;
+            if (mB) job.tile_nnmax[trow + tA + 1] = 1;
+        }
     }
     if (interior && yi < g.rows) {
         const size_t o = (size_t)yi * g.nx + xi;
@@ -178,169 +228,6 @@ __global__ __launch_bounds__(256) void k_prep(DiagJob<T> job) {
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------
-// Global-memory search for cells whose window outgrows the LDS tile (rare).
-// Rings are accumulated from the centre outwards; the first radius >= 1 at which the
-// square holds both classes is the reference's final nn (its sums restart at every
-// radius, so only that last square matters; ref: generic/sea_breeze_diag.f90:191-216).
-// ------------------------------------------------------------------------------------
-template <typename T>
-__device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &nn_used, bool &one_class) {
-    const Geo g = job.g;
-    int X, Y;
-    bool has_l = false, has_s = false;
-    if (sb_map_cell(g, x, y, X, Y)) {
-        if (sb_bit(job.clsbits, g.nw, X, Y)) has_l = true; else has_s = true;
-    }
-    int nn = 0;
-    bool found = false;
-    while (nn < cap) {
-        ++nn;
-        for (int e = -nn; e <= nn; ++e) {
-            const int xs[4] = {x + e, x + e, x - nn, x + nn};
-            const int ys[4] = {y - nn, y + nn, y + e, y + e};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (sb_map_cell(g, xs[q], ys[q], X, Y)) {
-                    if (sb_bit(job.clsbits, g.nw, X, Y)) has_l = true; else has_s = true;
-                }
-        }
-        if (has_l && has_s) { found = true; break; }
-    }
-    nn_used = nn;
-    one_class = !found;
-    // direct sums over the final square, offset by the centre value to keep the
-    // accumulations small
-    sb_map_cell(g, x, y, X, Y);
-    const double c0 = (double)job.t0[(size_t)Y * g.nxh + X];
-    double sl = 0.0, ss = 0.0;
-    double nl = 0.0, ns = 0.0;
-    for (int yy = y - nn; yy <= y + nn; ++yy)
-        for (int xx = x - nn; xx <= x + nn; ++xx) {
-            if (!sb_map_cell(g, xx, yy, X, Y)) continue;
-            const double d = (double)job.t0[(size_t)Y * g.nxh + X] - c0;
-            if (sb_bit(job.clsbits, g.nw, X, Y)) { sl += d; nl += 1.0; } else { ss += d; ns += 1.0; }
-        }
-    return (T)(sl / nl - ss / ns);               // 0/0 -> NaN when a class is missing
-}
-
-// ------------------------------------------------------------------------------------
-// k_thc: thermal heating contrast on TX x TY tiles with an LDS halo of H cells.
-// ------------------------------------------------------------------------------------
-template <typename T, int TX, int TY, int H, int NT>
-__global__ __launch_bounds__(NT) void k_thc(DiagJob<T> job) {
-    constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
-    constexpr int CPT = TX * TY / NT;            // cells per thread
-    static_assert(TX == 64, "a wave owns one 64-cell row segment");
-    static_assert((TX * TY) % NT == 0 && NT % TX == 0, "tile/thread shape");
-    static_assert((size_t)W * HT < 65536, "u16 count table");
-    __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
-    __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
-    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
-
-    const Geo g = job.g;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int lx = tid % TX, ly0 = tid / TX;
-
-    // which of my cells are in the band?
-    unsigned mine = 0;
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        const int x = x0 + lx, y = y0 + ly0 + q * (NT / TX);
-        if (x < g.nx && y < g.rows && sb_bit(job.bandbits, g.nw, x + g.h, y + g.h)) mine |= 1u << q;
-    }
-    if (!__syncthreads_or((int)mine)) {
-        if (tid == 0) job.tile_nnmax[blockIdx.y * gridDim.x + blockIdx.x] = 0;
-        return;
-    }
-
-    // ---- stage the tile + halo through the index map ---------------------------------
-    int X, Y;
-    sb_map_cell(g, x0, y0, X, Y);
-    const double c0 = (double)job.t0[(size_t)Y * g.nxh + X];
-    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
-    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
-    for (int i = tid; i < W * HT; i += NT) {
-        const int r = i / W, c = i - r * W;
-        double d = 0.0;
-        int land = 0;
-        if (sb_map_cell(g, x0 - H + c, y0 - H + r, X, Y)) {
-            d = (double)job.t0[(size_t)Y * g.nxh + X] - c0;
-            land = sb_bit(job.clsbits, g.nw, X, Y);
-        }
-        const int o = (r + 1) * P + c + 1;
-        sA[o] = d;
-        sL[o] = land ? d : 0.0;
-        sC[o] = (unsigned short)land;
-    }
-    __syncthreads();
-    // ---- prefix along latitude: one task per (table, column) ------------------------
-    for (int task = tid; task < 3 * W; task += NT) {
-        const int a = task / W, c = task - a * W + 1;
-        if (a == 0) { double s = 0.0; for (int r = 1; r <= HT; ++r) { s += sA[r * P + c]; sA[r * P + c] = s; } }
-        else if (a == 1) { double s = 0.0; for (int r = 1; r <= HT; ++r) { s += sL[r * P + c]; sL[r * P + c] = s; } }
-        else { unsigned s = 0; for (int r = 1; r <= HT; ++r) { s += sC[r * P + c]; sC[r * P + c] = (unsigned short)s; } }
-    }
-    __syncthreads();
-    // ---- prefix along longitude: one task per (table, row) --------------------------
-    for (int task = tid; task < 3 * HT; task += NT) {
-        const int a = task / HT, r = task - a * HT + 1;
-        if (a == 0) { double s = 0.0; for (int c = 1; c <= W; ++c) { s += sA[r * P + c]; sA[r * P + c] = s; } }
-        else if (a == 1) { double s = 0.0; for (int c = 1; c <= W; ++c) { s += sL[r * P + c]; sL[r * P + c] = s; } }
-        else { unsigned s = 0; for (int c = 1; c <= W; ++c) { s += sC[r * P + c]; sC[r * P + c] = (unsigned short)s; } }
-    }
-    __syncthreads();
-
-    // ---- expanding-window search, O(1) per radius ------------------------------------
-    int nnmax = 0;
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        if (!(mine & (1u << q))) continue;
-        const int ly = ly0 + q * (NT / TX);
-        const int x = x0 + lx, y = y0 + ly;
-        const int cx = lx + H, cy = ly + H;
-        int lim = H;
-        if (g.bnd == BND_HALO) {
-            int e = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
-            lim = min(lim, e);
-        }
-        int nn = 1, nl = 0, area = 0;
-        bool found = false;
-        for (; nn <= lim; ++nn) {
-            const int r0 = (cy - nn) * P, r1 = (cy + nn + 1) * P, c0i = cx - nn, c1i = cx + nn + 1;
-            nl = (int)sC[r1 + c1i] - (int)sC[r0 + c1i] - (int)sC[r1 + c0i] + (int)sC[r0 + c0i];
-            area = (2 * nn + 1) * (2 * nn + 1);
-            if (nl > 0 && nl < area) { found = true; break; }
-        }
-        T contrast;
-        if (found) {
-            const int r0 = (cy - nn) * P, r1 = (cy + nn + 1) * P, c0i = cx - nn, c1i = cx + nn + 1;
-            const double RL = (sL[r1 + c1i] - sL[r0 + c1i]) - (sL[r1 + c0i] - sL[r0 + c0i]);
-            const double RA = (sA[r1 + c1i] - sA[r0 + c1i]) - (sA[r1 + c0i] - sA[r0 + c0i]);
-            contrast = (T)(RL / (double)nl - (RA - RL) / (double)(area - nl));
-        } else {
-            int cap = g.nx + g.ny;
-            if (g.bnd == BND_HALO)
-                cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
-            bool one_class;
-            contrast = contrast_global(job, x, y, cap, nn, one_class);
-            atomicAdd(&job.counters[0], 1);
-            if (one_class) atomicAdd(&job.counters[1], 1);
-        }
-        nnmax = max(nnmax, nn);
-        const T mul = sb_bit(job.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);   // ref :182-186
-        job.thc[(size_t)y * g.nx + x] = mul * contrast;        // ref :216, :262
-    }
-    // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters)
-    __shared__ int s_nn;
-    if (tid == 0) s_nn = 0;
-    __syncthreads();
-    if (nnmax) atomicMax(&s_nn, nnmax);
-    __syncthreads();
-    if (tid == 0) job.tile_nnmax[blockIdx.y * gridDim.x + blockIdx.x] = s_nn;
 }
 
 // ------------------------------------------------------------------------------------
@@ -362,21 +249,26 @@ __global__ __launch_bounds__(256) void k_wind(DiagJob<T> job) {
     // ref: generic/sea_breeze_diag.f90:223 (per column), seabreeze_diag_python.f90:228 (1-D p)
     int lev = 0;
     if (job.flavour == SB_FLAVOUR_GENERIC) {
+        // 14 independent streaming loads in flight per lane (4 trips for the 56-level stub
+        // layout, ref: generic/get_all_fields_mod.f90:9); each level is a separate plane so
+        // a wave reads one contiguous 64-cell segment per level.  Non-temporal: the column
+        // is read once per call.
         const T *pc = job.p + o;
-        T best = fabs(pc[0] - job.target_plev);
+        T best = fabs(__builtin_nontemporal_load(pc) - job.target_plev);
         int k = 1;
-        for (; k + 8 <= nz; k += 8) {
-            T d[8];
+        constexpr int UN = 14;
+        for (; k + UN <= nz; k += UN) {
+            T d[UN];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] = pc[(size_t)(k + q) * pl];
+            for (int q = 0; q < UN; ++q) d[q] = __builtin_nontemporal_load(pc + (size_t)(k + q) * pl);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < UN; ++q) {
                 const T a = fabs(d[q] - job.target_plev);
                 if (a < best) { best = a; lev = k + q; }
             }
         }
         for (; k < nz; ++k) {
-            const T a = fabs(pc[(size_t)k * pl] - job.target_plev);
+            const T a = fabs(__builtin_nontemporal_load(pc + (size_t)k * pl) - job.target_plev);
             if (a < best) { best = a; lev = k; }
         }
     } else {
@@ -426,13 +318,20 @@ __global__ __launch_bounds__(256) void k_wind(DiagJob<T> job) {
 // ------------------------------------------------------------------------------------
 template <typename T>
 hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials,
-                           unsigned int *ticket, T *stats, hipStream_t st) {
+                           unsigned int *ticket, T *stats, Moments *moments_out, hipStream_t st) {
+    // one workgroup per CU, fewer when the field is small (8 elements per thread per trip)
     const size_t n = (size_t)nx * ny;
     int nblk = (int)((n + (size_t)STATS_NT * 8 - 1) / ((size_t)STATS_NT * 8));
     if (nblk < 1) nblk = 1;
-    if (nblk > SB_STATS_MAX_BLOCKS) nblk = SB_STATS_MAX_BLOCKS;
+    if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(k_stats<T>, dim3(nblk), dim3(STATS_NT), 0, st, ary, nx, ny, ld, off0, partials, ticket,
-                       stats);
+                       stats, moments_out);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t sb_launch_merge_moments(const Moments *parts, int nparts, T *stats, hipStream_t st) {
+    hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, parts, nparts, stats);
     return hipGetLastError();
 }
 
@@ -444,45 +343,34 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
     return hipGetLastError();
 }
 
-template <typename T, int H>
-static void launch_thc(const DiagJob<T> &job, hipStream_t st) {
-    constexpr int TX = 64, TY = (H <= 16 ? 32 : 16), NT = 512;
-    dim3 grid((job.g.nx + TX - 1) / TX, (job.g.rows + TY - 1) / TY);
-    hipLaunchKernelGGL((k_thc<T, TX, TY, H, NT>), grid, dim3(NT), 0, st, job);
-}
-
-template <typename T>
-void sb_thc_tiles(int nx, int rows, int H, int &tx, int &ty) {
-    const int TY = (H <= 16 ? 32 : 16);
-    tx = (nx + 63) / 64;
-    ty = (rows + TY - 1) / TY;
-}
-
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, Moments *partials, unsigned int *ticket, T *stats,
-                          hipStream_t st) {
+                          hipStream_t st, hipEvent_t *ev, const Moments *gathered, int ngathered, int ncu) {
     const Geo &g = job.g;
-    // sigmoid statistics over the interior of sigma
-    hipError_t e = sb_launch_stats<T>(job.sigma, g.nx, g.ny, g.nxh, (size_t)g.h * g.nxh + g.h, partials, ticket,
-                                      stats, st);
+    if (ev) (void)hipEventRecord(ev[0], st);
+    // sigmoid statistics: over the interior of sigma, or merged from the bands' gathered moments
+    hipError_t e = gathered ? sb_launch_merge_moments<T>(gathered, ngathered, stats, st)
+                            : sb_launch_stats<T>(job.sigma, g.nx, g.ny, g.nxh, (size_t)g.h * g.nxh + g.h, partials,
+                                                 ticket, stats, nullptr, st);
     if (e != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_prep<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-    if (H <= 8) launch_thc<T, 8>(job, st);
-    else if (H <= 16) launch_thc<T, 16>(job, st);
-    else launch_thc<T, 24>(job, st);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    e = sb_launch_thc<T>(job, H, ncu, st);
+    if (e != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[3], st);
     hipLaunchKernelGGL(k_wind<T>, dim3((g.nx + 255) / 256, g.rows), dim3(256), 0, st, job);
+    if (ev) (void)hipEventRecord(ev[4], st);
     return hipGetLastError();
 }
 
 template hipError_t sb_launch_stats<float>(const float *, int, int, int, size_t, Moments *, unsigned int *, float *,
-                                           hipStream_t);
+                                           Moments *, hipStream_t);
 template hipError_t sb_launch_stats<double>(const double *, int, int, int, size_t, Moments *, unsigned int *,
-                                            double *, hipStream_t);
+                                            double *, Moments *, hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<float>(const float *, float *, size_t, const float *, hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<double>(const double *, double *, size_t, const double *, hipStream_t);
 template hipError_t sb_launch_diag<float>(const DiagJob<float> &, int, Moments *, unsigned int *, float *,
-                                          hipStream_t);
+                                          hipStream_t, hipEvent_t *, const Moments *, int, int);
 template hipError_t sb_launch_diag<double>(const DiagJob<double> &, int, Moments *, unsigned int *, double *,
-                                           hipStream_t);
-template void sb_thc_tiles<float>(int, int, int, int &, int &);
-template void sb_thc_tiles<double>(int, int, int, int &, int &);
+                                           hipStream_t, hipEvent_t *, const Moments *, int, int);

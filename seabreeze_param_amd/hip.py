@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseabreeze_hip.so")
+LIB_PATH = os.environ.get("SEABREEZE_HIP_LIB", os.path.join(_HERE, "libseabreeze_hip.so"))
 
 SB_BND_WRAPPER, SB_BND_GLOBAL, SB_BND_HALO = 0, 1, 2
 
@@ -100,6 +100,16 @@ class Context:
         arr = (C.c_longlong * 4)()
         self._chk(self.lib.sb_last_counters(self.h, arr), "sb_last_counters")
         return dict(band_cells=arr[0], global_path_cells=arr[1], one_class_cells=arr[2], max_radius=arr[3])
+
+    def profile_begin(self, max_calls: int):
+        self._chk(self.lib.sb_profile_begin(self.h, C.c_int(max_calls)), "sb_profile_begin")
+
+    def profile_end(self):
+        """-> ({'k_stats': ms, 'k_prep': ms, 'k_thc': ms, 'k_wind': ms}, ncalls), HIP-event averages."""
+        ms = (C.c_double * 4)()
+        n = C.c_int(0)
+        self._chk(self.lib.sb_profile_end(self.h, ms, C.byref(n)), "sb_profile_end")
+        return dict(k_stats=ms[0], k_prep=ms[1], k_thc=ms[2], k_wind=ms[3]), n.value
 
     # ------------------------------------------------------------------ host-pointer API
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
@@ -188,6 +198,18 @@ class Context:
                 _p(thc), _p(sb_con), C.byref(tunables) if tunables is not None else None,
                 C.c_void_p(stream) if stream else None)
         self._chk(rc, "sb_seabreeze_diag_dev")
+
+
+    def sigma_moments_dev(self, dtype, nx, ny, halo, sigma, moments5, stream=None):
+        """Band-local sigma moments -> 5 doubles at device address moments5."""
+        fn = getattr(self.lib, f"sb_sigma_moments_{_SFX[np.dtype(dtype)]}_dev")
+        self._chk(fn(self.h, C.c_int(nx), C.c_int(ny), C.c_int(halo), _p(sigma), _p(moments5),
+                     C.c_void_p(stream) if stream else None), "sb_sigma_moments_dev")
+
+    def use_gathered_moments(self, gathered, nparts: int):
+        """Following diag calls merge `nparts` gathered moments (device address) instead of scanning sigma."""
+        self._chk(self.lib.sb_use_gathered_moments(self.h, _p(gathered) if gathered else None, C.c_int(nparts)),
+                  "sb_use_gathered_moments")
 
 
 def dist_window(lon, lat, maxdist=180.0) -> int:
