@@ -107,8 +107,16 @@ class Oracle:
         return output
 
     # -- generic-flavour seabreeze_diag (state + sb_con updated IN PLACE) ------
+    def sigmoid_scalars(self, ary):
+        """(std, r) of the logistic for a field (generic/sea_breeze_diag.f90:466-479)."""
+        ary = _f(ary, self.dt)
+        ny, nx = ary.shape
+        sd, r = self.ct(0), self.ct(0)
+        self.lib.sbo_sigmoid_scalars(_ptr(ary), C.c_int(nx), C.c_int(ny), C.byref(sd), C.byref(r))
+        return sd.value, r.value
+
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
-                       halo=0, bnd=1, omp=False):
+                       halo=0, bnd=1, omp=False, ext_stats=None):
         dt, ct = self.dt, self.ct
         p = _f(p, dt); u = _f(u, dt); v = _f(v, dt)
         theta = _f(theta, dt); mask = _f(mask, dt); z = _f(z, dt); sigma = _f(sigma, dt)
@@ -124,10 +132,13 @@ class Oracle:
                 _ptr(z), _ptr(sigma), _ptr(ws), _ptr(wd), _ptr(thc), _ptr(sb_con),
                 C.c_int(nx), C.c_int(ny), C.c_int(nz))
             return sb_con
-        self.lib.sbo_seabreeze_diag(
+        use_ext = 0 if ext_stats is None else 1
+        es, er = (0.0, 0.0) if ext_stats is None else ext_stats
+        self.lib.sbo_seabreeze_diag_x(
             ct(timestep), C.c_int(tn), _ptr(p), _ptr(u), _ptr(v), _ptr(theta), _ptr(mask),
             _ptr(z), _ptr(sigma), _ptr(ws), _ptr(wd), _ptr(thc), _ptr(sb_con),
-            C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo), C.c_int(bnd), C.byref(nn))
+            C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo), C.c_int(bnd),
+            C.c_int(use_ext), ct(es), ct(er), C.byref(nn))
         self.last_nn_max = nn.value
         return sb_con
 

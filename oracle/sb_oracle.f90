@@ -252,6 +252,43 @@ contains
     real, intent(inout) :: windspeed(nlons,nlats), winddir(nlons,nlats)
     real, intent(inout) :: thc(nlons,nlats), sb_con(nlons,nlats)
     integer(c_int), intent(out) :: nn_max
+    call sbo_seabreeze_diag_x(timestep, tn, p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con, &
+                              nlons, nlats, nz, h, bnd, 0, 0., 0., nn_max)
+  end subroutine sbo_seabreeze_diag
+
+  ! scalars of the logistic (std, r) for a field, ref: generic/sea_breeze_diag.f90:466-479
+  subroutine sbo_sigmoid_scalars(ary, nlons, nlats, std, r) bind(C, name='sbo_sigmoid_scalars')
+    integer(c_int), value, intent(in) :: nlons, nlats
+    real, intent(in)  :: ary(nlons, nlats)
+    real, intent(out) :: std, r
+    real :: mean, var
+    integer :: i, j
+    mean = sum(ary) / (nlons*nlats)
+    var = 0
+    do i = 1, nlats
+      do j = 1, nlons
+        var = var + (ary(j,i) - mean)**2
+      end do
+    end do
+    std = 2 / sqrt(var / (nlons*nlats))
+    r = (maxval(ary) - minval(ary)) / 4.
+  end subroutine sbo_sigmoid_scalars
+
+  ! As sbo_seabreeze_diag; with use_ext /= 0 the logistic scalars come from the caller
+  ! (the GLOBAL field's std and r) instead of this sub-domain's sigma: what one latitude
+  ! band of a decomposed grid has to use to reproduce the single-domain result.
+  subroutine sbo_seabreeze_diag_x(timestep, tn, p, u, v, theta, mask, z, sigma, &
+                                windspeed, winddir, thc, sb_con, &
+                                nlons, nlats, nz, h, bnd, use_ext, ext_std, ext_r, nn_max) &
+      bind(C, name='sbo_seabreeze_diag_x')
+    real, value, intent(in) :: timestep, ext_std, ext_r
+    integer(c_int), value, intent(in) :: tn, nlons, nlats, nz, h, bnd, use_ext
+    real, intent(in) :: p(nlons,nlats,nz), u(nlons,nlats,nz), v(nlons,nlats,nz)
+    real, intent(in) :: theta(1-h:nlons+h,1-h:nlats+h), mask(1-h:nlons+h,1-h:nlats+h)
+    real, intent(in) :: z(1-h:nlons+h,1-h:nlats+h), sigma(1-h:nlons+h,1-h:nlats+h)
+    real, intent(inout) :: windspeed(nlons,nlats), winddir(nlons,nlats)
+    real, intent(inout) :: thc(nlons,nlats), sb_con(nlons,nlats)
+    integer(c_int), intent(out) :: nn_max
     real, parameter :: target_plev = 100 * 700., thresh_wind = 11., thresh_winddir = 90.
     real, parameter :: thresh_windch = 5., thresh_thc = 0.75, target_time = 6.*60**2
     real, parameter :: maxdist = 180.
@@ -261,25 +298,22 @@ contains
     logical :: refresh
 
     allocate(t0(1-h:nlons+h,1-h:nlats+h))
-    if (h == 0) then
+    if (h == 0 .and. use_ext == 0) then
       allocate(s_sm(nlons,nlats))
       call sbo_sigmoid(sigma, nlons, nlats, s_sm)
       t0 = theta - (c_gmma * z * s_sm)
       deallocate(s_sm)
     else
-      ! statistics from the interior, logistic applied to ghost cells too
-      allocate(s_in(nlons,nlats))
-      s_in = sigma(1:nlons,1:nlats)
-      mean = sum(s_in) / (nlons*nlats)
-      var = 0
-      do i = 1, nlats
-        do j = 1, nlons
-          var = var + (s_in(j,i) - mean)**2
-        end do
-      end do
-      std = 2 / sqrt(var / (nlons*nlats))
-      r = (maxval(s_in) - minval(s_in)) / 4.
-      deallocate(s_in)
+      if (use_ext /= 0) then
+        std = ext_std
+        r = ext_r
+      else
+        ! statistics from the interior, logistic applied to ghost cells too
+        allocate(s_in(nlons,nlats))
+        s_in = sigma(1:nlons,1:nlats)
+        call sbo_sigmoid_scalars(s_in, nlons, nlats, std, r)
+        deallocate(s_in)
+      end if
       t0 = theta - (c_gmma * z * (1 / (1 + exp(-std*(sigma - r)))))
     end if
 
@@ -309,7 +343,7 @@ contains
       end do
     end do
     deallocate(t0)
-  end subroutine sbo_seabreeze_diag
+  end subroutine sbo_seabreeze_diag_x
 
   !-----------------------------------------------------------------------------
   ! coastline by binary 3x3 Sobel.

@@ -1,0 +1,294 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Tolerances
+  fp64: 1e-6 relative (BASELINE.json north_star), asserted here at 1e-7 with an absolute
+        floor of 1e-9 K / m s^-1 for values that cancel to ~0; coast mask bit-exact.
+  fp32: the reference itself accumulates up to (2*16+1)^2 values near 290 K sequentially in
+        fp32 (seabreeze_diag_python.f90:204-209), which costs it ~1e-4 K in each window
+        mean; the HIP path keeps the window sums in fp64.  Fields that do not pass through
+        that sum (t0, windspeed, winddir, distances) are held to 2e-6 relative; thc to 2e-3 K
+        absolute; sb_con is compared where neither side sits within 5e-3 K of the 0.75 K
+        threshold.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+from seabreeze_param_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rel=1e-7, floor=1e-9)
+
+
+def _states(ny, nx, dt, n):
+    return [np.zeros((ny, nx), dt) for _ in range(n)]
+
+
+def _assert_close64(a, b, what):
+    e = relerr(a, b, floor=1e-2)      # relative to max(|b|, 1e-2): |err| <= 1e-7*|b| or 1e-9 absolute
+    assert e < F64["rel"], f"{what}: rel err {e}"
+
+
+# ----------------------------------------------------------------------------------------
+# golden fixtures (outputs of the reference's own Fortran)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["diag_96x72", "diag_96x72_default"])
+def test_golden_diag_fp64(hipctx, case):
+    g = golden(case)
+    dt = np.float64
+    ny, nx = g["lsm"].shape
+    maxdist, timestep = float(g["maxdist"]), float(g["timestep"])
+    coast = hipctx.get_edges(g["lsm"].astype(dt), g["ci"].astype(dt))
+    assert np.array_equal(coast, g["coast_r8"])
+    cdist = hipctx.get_dist(coast, g["lsm"].astype(dt), g["lon"].astype(dt), g["lat"].astype(dt), maxdist=maxdist)
+    _assert_close64(cdist, g["cdist_r8"], "cdist")
+    assert np.array_equal(np.sign(cdist), np.sign(g["cdist_r8"]))
+    _assert_close64(hipctx.sigmoid(g["std"].astype(dt)), g["sigmoid_r8"], "sigmoid")
+    ws, wd, thc = _states(ny, nx, dt, 3)
+    for t in range(g["theta"].shape[0]):
+        out = np.full((4, ny, nx), -777.0, dt)
+        hipctx.diag(t + 1, g["p"], g["z"], g["std"], g["theta"][t], g["v"][t], g["u"][t], g["cdist_r8"],
+                    ws, wd, thc, output=out, maxdist=maxdist, timestep=timestep)
+        ref = g["output_r8"][t]
+        assert np.all(out[:, -1] == -777.0), "row nlats must stay untouched"
+        fill = ref[0, :-1] > 1e19
+        assert np.array_equal(out[0, :-1] > 1e19, fill)
+        for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+            _assert_close64(out[k, :-1], ref[k, :-1], f"{case} step {t + 1} {nm}")
+        _assert_close64(thc, g["thc_r8"][t], f"{case} step {t + 1} thc")
+        assert np.array_equal(out[0, :-1] != 0, ref[0, :-1] != 0), "trigger pattern differs"
+    _assert_close64(ws, g["ws_final_r8"], "final windspeed")
+    _assert_close64(wd, g["wd_final_r8"], "final winddir")
+
+
+def test_golden_diag_fp32(hipctx):
+    g = golden("diag_96x72")
+    dt = np.float32
+    ny, nx = g["lsm"].shape
+    maxdist, timestep = float(g["maxdist"]), float(g["timestep"])
+    coast = hipctx.get_edges(g["lsm"], g["ci"])
+    assert np.array_equal(coast, g["coast_r4"])
+    cdist = hipctx.get_dist(coast, g["lsm"], g["lon"], g["lat"], maxdist=maxdist)
+    assert relerr(cdist, g["cdist_r4"]) < 2e-6
+    ws, wd, thc = _states(ny, nx, dt, 3)
+    for t in range(g["theta"].shape[0]):
+        out = np.zeros((4, ny, nx), dt)
+        hipctx.diag(t + 1, g["p"], g["z"], g["std"], g["theta"][t], g["v"][t], g["u"][t], g["cdist_r4"],
+                    ws, wd, thc, output=out, maxdist=maxdist, timestep=timestep)
+        ref = g["output_r4"][t]
+        assert relerr(out[1, :-1], ref[1, :-1]) < 2e-6                  # t0
+        assert np.max(np.abs(thc - g["thc_r4"][t])) < 2e-3
+        near = np.abs(np.abs(g["thc_r4"][t][:-1]) - 0.75) < 5e-3
+        band = ref[0, :-1] < 1e19
+        ok = band & ~near
+        assert np.max(np.abs(out[0, :-1][ok] - ref[0, :-1][ok])) < 5e-3
+        assert np.array_equal(out[0, :-1][~band], ref[0, :-1][~band])
+        # winds: state carried only through refreshes, no window sum involved
+        assert relerr(out[2, :-1], ref[2, :-1], floor=1e-3) < 2e-6
+        assert relerr(out[3, :-1], ref[3, :-1], floor=1e-1) < 2e-6
+
+
+def test_golden_coast(hipctx):
+    g = golden("coast_256x192")
+    for prec, dt, tol in ((8, np.float64, 1e-9), (4, np.float32, 2e-6)):
+        lsm, ci = g["lsm"].astype(dt), g["ci"].astype(dt)
+        coast = hipctx.get_edges(lsm, ci)
+        assert np.array_equal(coast, g[f"coast_r{prec}"])
+        cdist = hipctx.get_dist(coast, lsm, g["lon"].astype(dt), g["lat"].astype(dt), maxdist=float(g["maxdist"]))
+        assert relerr(cdist, g[f"cdist_r{prec}"]) < tol
+        assert np.array_equal(np.sign(cdist), np.sign(g[f"cdist_r{prec}"]))
+
+
+# ----------------------------------------------------------------------------------------
+# HIP vs oracle on seeded synthetic grids, both flavours, ragged sizes
+# ----------------------------------------------------------------------------------------
+SHAPES = [(96, 72, 3), (256, 192, 5), (130, 75, 2), (63, 40, 1), (200, 33, 4), (1024, 768, 6)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wrapper_flavour_fp64(hipctx, oracles, shape):
+    nx, ny, nz = shape
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt, fractional_coast=True)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    assert np.array_equal(hipctx.get_edges(st.landfrac, st.icefrac), coast)
+    maxdist = 180.0 if nx >= 1024 else 700.0
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=maxdist)
+    _assert_close64(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=maxdist), cdist, "cdist")
+    p = synth.pressure_1d(nz, dt)
+    so, sh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
+    for tn in range(1, 6):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        oo = orc.diag(tn, p, st.z, st.sigma, th, v, u, cdist, *so, maxdist=maxdist, timestep=90.0)
+        oh = hipctx.diag(tn, p, st.z, st.sigma, th, v, u, cdist, *sh, maxdist=maxdist, timestep=90.0)
+        for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+            _assert_close64(oh[k, :-1], oo[k, :-1], f"{shape} tn={tn} {nm}")
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc")):
+            _assert_close64(a, b, f"{shape} tn={tn} state {nm}")
+        assert np.array_equal(oh[0, :-1] != 0, oo[0, :-1] != 0)
+    c = hipctx.last_counters()
+    assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("bnd", [hip.SB_BND_GLOBAL, hip.SB_BND_WRAPPER])
+def test_generic_flavour_fp64(hipctx, oracles, shape, bnd):
+    nx, ny, nz = shape
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+    assert np.array_equal(hipctx.get_edges(st.landfrac, st.icefrac, rule=1, bnd=hip.SB_BND_GLOBAL), coast)
+    kw = 4 if nx < 1024 else 6
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=kw)   # generic: fixed +-halo window
+    _assert_close64(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=kw), cdist, "cdist")
+    cdist[np.abs(cdist) > 180.0] = 12000.0
+    p = synth.pressure_3d(st, nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    for a in so + sh:
+        a[:] = 3.25                                   # cells outside the band must keep this
+    for tn in range(1, 5):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=bnd)
+        hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=bnd)
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+            _assert_close64(a, b, f"{shape} bnd={bnd} tn={tn} {nm}")
+        assert np.array_equal(sh[3] != 0, so[3] != 0)
+    off = np.abs(cdist) > 180.0
+    assert np.all(sh[3][off] == 0.0) and all(np.all(a[off] == 3.25) for a in sh[:3])
+
+
+@pytest.mark.parametrize("shape", [(96, 72, 3), (256, 192, 2)])
+def test_wrapper_flavour_fp32(hipctx, oracles, shape):
+    nx, ny, nz = shape
+    dt, orc = np.float32, oracles[4]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    assert np.array_equal(hipctx.get_edges(st.landfrac, st.icefrac), coast)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=700.0)
+    assert relerr(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=700.0), cdist) < 2e-6
+    assert relerr(hipctx.sigmoid(st.sigma), orc.sigmoid(st.sigma)) < 5e-6
+    p = synth.pressure_1d(nz, dt)
+    so, sh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
+    for tn in range(1, 4):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        oo = orc.diag(tn, p, st.z, st.sigma, th, v, u, cdist, *so, maxdist=700.0, timestep=90.0)
+        oh = hipctx.diag(tn, p, st.z, st.sigma, th, v, u, cdist, *sh, maxdist=700.0, timestep=90.0)
+        assert relerr(oh[1, :-1], oo[1, :-1]) < 2e-6
+        assert np.max(np.abs(sh[2] - so[2])) < 2e-3
+        near = np.abs(np.abs(so[2][:-1]) - 0.75) < 5e-3
+        ok = (oo[0, :-1] < 1e19) & ~near
+        assert np.max(np.abs(oh[0, :-1][ok] - oo[0, :-1][ok])) < 5e-3
+
+
+# ----------------------------------------------------------------------------------------
+# halo'd (band) arrays, search radius beyond the LDS tile, degenerate grids
+# ----------------------------------------------------------------------------------------
+def test_halo_mode_matches_oracle(hipctx, oracles):
+    nx, ny, nz, h = 160, 96, 3, 7
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx + 2 * h, ny + 2 * h, dt)          # a bigger field whose rim serves as ghosts
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cd = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=900.0, kwin=h - 1)
+    cd[np.abs(cd) > 180.0] = 12000.0
+    core = (slice(h, h + ny), slice(h, h + nx))
+    p = synth.pressure_3d(st, nz, dt)[:, core[0], core[1]].copy()
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    for tn in range(1, 4):
+        th = synth.theta_step(st, tn, dt)
+        u, v = (a[:, core[0], core[1]].copy() for a in synth.wind_step(st, nz, tn, dt))
+        orc.seabreeze_diag(7200.0, tn, p, u, v, th, cd, st.z, st.sigma, *so, halo=h, bnd=2)
+        hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cd, st.z, st.sigma, *sh, halo=h, bnd=hip.SB_BND_HALO)
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+            _assert_close64(a, b, f"halo tn={tn} {nm}")
+
+
+def test_search_radius_beyond_lds_halo(hipctx, oracles):
+    """Radius hint 8 but radii up to ~13: cells past the LDS halo take the global-memory path
+    and must give the same numbers."""
+    nx, ny, nz = 256, 192, 2
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=5000.0, kwin=12)
+    p = synth.pressure_1d(nz, dt)
+    th = synth.theta_step(st, 1, dt)
+    u, v = synth.wind_step(st, nz, 1, dt)
+    so, sh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
+    oo = orc.diag(1, p, st.z, st.sigma, th, v, u, cdist, *so, maxdist=5000.0)
+    hipctx.set_search_radius_hint(8)
+    try:
+        oh = hipctx.diag(1, p, st.z, st.sigma, th, v, u, cdist, *sh, maxdist=5000.0)
+        c = hipctx.last_counters()
+    finally:
+        hipctx.set_search_radius_hint(16)
+    assert orc.last_nn_max > 8 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
+    for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+        _assert_close64(oh[k, :-1], oo[k, :-1], nm)
+    _assert_close64(sh[2], so[2], "thc")
+
+
+def test_no_band_and_one_class(hipctx):
+    nx, ny, nz = 70, 20, 2
+    dt = np.float64
+    rng = np.random.default_rng(1)
+    p = synth.pressure_1d(nz, dt)
+    z = rng.uniform(0, 500, (ny, nx)); sg = rng.uniform(0, 50, (ny, nx)); th = rng.uniform(280, 300, (ny, nx))
+    u = rng.normal(size=(nz, ny, nx)); v = rng.normal(size=(nz, ny, nx))
+    # (a) nothing within maxdist: only the fill value / t0 plane are written
+    far = np.full((ny, nx), 12000.0)
+    st3 = _states(ny, nx, dt, 3)
+    out = hipctx.diag(1, p, z, sg, th, v, u, far, *st3)
+    assert np.all(out[0, :-1] == 2.0e20) and np.all(out[2:, :-1] == 0) and all(np.all(a == 0) for a in st3)
+    assert hipctx.last_counters()["band_cells"] == 0
+    # (b) every cell in the band and on the land side: the reference's search never ends
+    #     (generic/sea_breeze_diag.f90:191-214); here it stops and yields NaN, counted
+    allland = np.full((ny, nx), 5.0)
+    out = hipctx.diag(1, p, z, sg, th, v, u, allland, *_states(ny, nx, dt, 3))
+    c = hipctx.last_counters()
+    assert c["one_class_cells"] == c["band_cells"] == nx * (ny - 1)
+    assert np.all(np.isnan(out[0, :-1]) | (out[0, :-1] == 0))
+
+
+# ----------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes (no oracle needed)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1024, 768, 8), (2560, 1920, 4)])
+def test_properties_at_full_size(hipctx, shape):
+    nx, ny, nz = shape
+    dt = np.float64
+    st = synth.static_fields(nx, ny, dt)
+    coast = hipctx.get_edges(st.landfrac, st.icefrac)
+    cdist = hipctx.get_dist(coast, st.landfrac, st.lon, st.lat)
+    assert np.all(np.abs(cdist[coast > 0]) == 0.5)
+    p = synth.pressure_3d(st, nz, dt)
+    th = synth.theta_step(st, 1, dt)
+    u, v = synth.wind_step(st, nz, 1, dt)
+    band = np.abs(cdist) <= 180.0
+
+    def run(theta, zz, shift=0, steps=2):
+        roll = (lambda a: np.ascontiguousarray(np.roll(a, shift, axis=-1))) if shift else (lambda a: a)
+        s = _states(ny, nx, dt, 4)
+        for tn in range(1, steps + 1):
+            hipctx.seabreeze_diag(10800.0, tn, roll(p), roll(u), roll(v), roll(theta), roll(cdist), roll(zz),
+                                  roll(st.sigma), *s, halo=0, bnd=hip.SB_BND_GLOBAL)
+        return s
+
+    base = run(th, st.z)
+    assert np.all(base[3][~band] == 0) and np.all(base[2][~band] == 0)
+    assert np.isfinite(base[3]).all() and (base[3] != 0).sum() > 0.2 * band.sum()
+    # idempotence: the same call sequence twice gives the same bits
+    again = run(th, st.z)
+    assert all(np.array_equal(a, b) for a, b in zip(base, again))
+    # longitude is periodic: rolling every input rolls every output (tile/wave boundaries move)
+    rolled = run(th, st.z, shift=37)
+    for a, b, nm in zip(rolled, base, ("ws", "wd", "thc", "sb_con")):
+        assert relerr(a, np.roll(b, 37, axis=-1), floor=1e-2) < 1e-7, nm
+    # the contrast is linear in temperature: with z = 0, thc(a*theta + b) = a * thc(theta)
+    z0 = np.zeros_like(st.z)
+    t1 = run(th, z0, steps=1)[2]
+    t2 = run(2.5 * th - 100.0, z0, steps=1)[2]
+    assert relerr(t2, 2.5 * t1, floor=1e-2) < 1e-7
