@@ -1,0 +1,116 @@
+"""Python driver layer over the `seabreeze` extension module (MI355X build).
+
+Counterpart of the reference's ``seabreezediag`` package
+(ref: python_wrapper/seabreezediag/__init__.py:13-40 ``c2f``, :91-263 ``diag``): same call
+signature, same array conventions, same return tuple, so scripts written against the
+reference keep working with ``import seabreezediag``.  The `seabreeze` module it imports
+is the f2py surface built from python_wrapper/seabreeze_f2py.f90, whose routines run on
+the GPU through libseabreeze_hip.so.
+
+Conventions kept from the reference
+  * 2-D fields are C-ordered ``(lat, lon)``, winds ``([time,] pres, lat, lon)``; ``c2f``
+    flips them into the Fortran ``(lon, lat[, pres])`` layout the kernels use.
+  * ``tt`` is the running timestep number (clamped to >= 1) and comes back advanced by the
+    number of steps processed.
+  * The second returned state array is the sea-level temperature t0 (output plane 2), which
+    the reference hands back under the name ``thc`` (ref :244); the
+    kernel never reads that state, so this is harmless and kept.
+  * The last latitude row of every output plane is never written by the kernel
+    (ref: seabreeze_diag_python.f90:165).
+
+Differences (both are crashes in the reference)
+  * ``ci=None`` works: no sea ice, the coast distance is computed once.
+  * inputs without a time axis work.
+"""
+import warnings
+
+import numpy as np
+
+from seabreeze import diag as _diag_kernel, get_dist, get_edges
+
+__all__ = ["diag", "c2f", "read_nc"]
+
+
+def c2f(array):
+    """Reinterpret a C-ordered array as the Fortran-ordered array with reversed shape
+    (for a C-contiguous input this is the transpose view, no copy)."""
+    array = np.asarray(array)
+    return array.ravel().reshape(array.shape[::-1], order="F")
+
+
+def _pop(kwargs, key, default=None):
+    return kwargs.pop(key) if key in kwargs else default
+
+
+def _coast_distance(lsm, ice, lon, lat):
+    return c2f(get_dist(get_edges(c2f(lsm), c2f(ice)), c2f(lsm), lon, lat))
+
+
+def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
+    """Potential sea-breeze convergence strength in the coastal band
+    (Bergemann et al. 2017, doi:10.1002/2017MS001048).
+
+    Positional: ``tt, lsm, z, std, lon, lat, pres, u, v, t, ci`` -- or pass ``meta=`` (an
+    object with attributes ``u, v, theta`` and optionally ``ci``) instead of the last four.
+    Keywords: state ``ws, wd, thc`` from the previous call (default zeros), plus the kernel
+    tunables ``target_plev`` [hPa], ``thresh_wind``, ``thresh_winddir``, ``thresh_windch``,
+    ``thresh_thc``, ``target_time`` [h], ``maxdist`` [km], ``timestep`` [min].
+
+    Returns ``(tt, sb_con, thc, ws, wd)``; ``sb_con`` is float64 ``(ntime, lat, lon)``.
+    """
+    ws, wd, thc = (_pop(kwargs, k) for k in ("ws", "wd", "thc"))
+    meta = _pop(kwargs, "meta")
+    if meta is None:
+        u, v, t, ci = args
+    else:
+        u, v, t = meta.u, meta.v, meta.theta
+        ci = getattr(meta, "ci", None)
+    tt = max(1, tt)
+    names = {"ws": "Windspeed", "wd": "Wind direction", "thc": "Heating contrast"}
+    state = {}
+    for key, val in (("ws", ws), ("wd", wd), ("thc", thc)):
+        if val is None:
+            if tt > 1:
+                warnings.warn(f"{names[key]} should be given from previous timestep")
+            val = np.zeros_like(lsm)
+        state[key] = val
+    ws, wd, thc = state["ws"], state["wd"], state["thc"]
+
+    has_time = np.ndim(v) > 3
+    nt = len(v) if has_time else 1
+    nlat, nlon = np.shape(t)[-2:]
+    out_all = np.zeros([4, nt, nlat, nlon])
+    dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
+    for ts in range(nt):
+        if ci is not None:
+            ice = ci[ts] if has_time else ci
+            ice = ice.filled(0) if hasattr(ice, "filled") else ice
+            dist = _coast_distance(lsm, ice, lon, lat)       # recomputed every step like the reference (:223-228)
+        tk, vk, uk = (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
+        out = c2f(_diag_kernel(tt, c2f(pres), c2f(z), c2f(std), c2f(tk), c2f(vk), c2f(uk), c2f(dist),
+                               c2f(ws), c2f(wd), c2f(thc), **kwargs))
+        out_all[:, ts] = out
+        thc, ws, wd = out[1], out[2], out[3]
+        tt += 1
+    return tt, out_all[0], thc, ws, wd
+
+
+def read_nc(fnv, fnu, fntheta, fnci, vv="v", vu="u", vtheta="t2m", vci="ci", vpres="pres", vtime="time"):
+    """Open the four NetCDF inputs and return an object usable as ``diag(..., meta=...)``
+    (ref: python_wrapper/seabreezediag/__init__.py:53-89).  Needs netCDF4, which this image
+    does not ship; the import is deferred so the rest of the package works without it."""
+    import os
+    from types import SimpleNamespace
+
+    from netCDF4 import Dataset, num2date
+
+    files = {"v": fnv, "u": fnu, "theta": fntheta, "ci": fnci}
+    varname = {"v": vv, "u": vu, "theta": vtheta, "ci": vci}
+    meta = SimpleNamespace(nc={k: Dataset(os.path.expanduser(f)) for k, f in files.items()})
+    for key, ds in meta.nc.items():
+        setattr(meta, key, ds.variables[varname[key]])
+    tvar = meta.nc["v"].variables[vtime]
+    meta.time = num2date(tvar[:], tvar.units)
+    meta.pres = meta.nc["v"].variables[vpres][:]
+    meta.dt = (meta.time[1] - meta.time[0]).seconds / 60.0
+    return meta

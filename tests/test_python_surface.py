@@ -1,0 +1,86 @@
+"""The Python surface: the f2py extension `seabreeze` (built from python_wrapper/
+seabreeze_f2py.f90) and the `seabreezediag` driver layer on top of it, against a golden
+captured from the reference's own Python package running on the reference's own f2py
+extension (tests/golden/make_golden_python.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+PW = os.path.join(ROOT, "python_wrapper")
+
+
+def _import_surface():
+    if PW not in sys.path:
+        sys.path.insert(0, PW)
+    import seabreeze
+    import seabreezediag
+    assert os.path.dirname(seabreeze.__file__) == PW, seabreeze.__file__
+    return seabreeze, seabreezediag
+
+
+def _built():
+    return any(f.startswith("seabreeze.") and f.endswith(".so") for f in os.listdir(PW))
+
+
+@pytest.mark.skipif(not _built(), reason="python_wrapper extension not built (run __graft_entry__.build())")
+def test_f2py_signatures_match_reference_surface():
+    """First docstring line of every routine == the signature f2py derives from the reference's
+    Fortran (measured from the reference's generated .pyf)."""
+    seabreeze, sbd = _import_surface()
+    sig = lambda f: f.__doc__.splitlines()[0].strip()
+    assert sig(seabreeze.diag) == ("output = diag(timestep_number,p,z,std,theta,v,u,cdist,windspeed,winddir,thc,"
+                                   "[target_plev,thresh_wind,thresh_winddir,thresh_windch,thresh_thc,target_time,"
+                                   "maxdist,timestep,nps,nlons,nlats])")
+    assert sig(seabreeze.get_edges) == "coast = get_edges(lsm,ci,[nlons,nlats])"
+    assert sig(seabreeze.get_dist) == "cdist = get_dist(coast,mask,lon,lat,[nlons,nlats,maxdist])"
+    assert sig(seabreeze.sigmoid) == "sm = sigmoid(ary,[nlons,nlats])"
+    assert sig(seabreeze.get_threads) == "nt = get_threads()"
+    assert "rank-2 array('f') with bounds (nlons,nlats)" in seabreeze.diag.__doc__
+    for name in ("diag", "c2f", "read_nc"):
+        assert hasattr(sbd, name)
+
+
+@pytest.mark.skipif(not _built(), reason="python_wrapper extension not built")
+def test_c2f_is_the_transpose_view():
+    _, sbd = _import_surface()
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    f = sbd.c2f(a)
+    assert f.shape == (4, 3, 2) and f.flags.f_contiguous and np.array_equal(f, a.T)
+    assert np.shares_memory(f, a)
+
+
+@pytest.mark.gpu
+def test_python_surface_matches_reference_golden():
+    assert _built(), "python_wrapper extension missing: __graft_entry__.build() makes it"
+    seabreeze, sbd = _import_surface()
+    g = golden("python_surface_96x72")
+    nt = g["sb1"].shape[0]
+    kw = dict(timestep=float(g["timestep"]), maxdist=float(g["maxdist"]))
+    args = (g["lsm"], g["z"], g["std"], g["lon"], g["lat"], g["pres"])
+    tt1, sb1, thc1, ws1, wd1 = sbd.diag(1, *args, g["u"][:nt], g["v"][:nt], g["t"][:nt], g["ci"][:nt], **kw)
+    tt2, sb2, thc2, ws2, wd2 = sbd.diag(tt1, *args, g["u"][nt:], g["v"][nt:], g["t"][nt:], g["ci"][nt:],
+                                        ws=ws1, wd=wd1, thc=thc1, **kw)
+    assert (tt1, tt2) == (int(g["tt1"]), int(g["tt2"]))
+    assert sb1.shape == g["sb1"].shape and sb1.dtype == np.float64
+    assert ws1.shape == g["ws1"].shape
+    assert seabreeze.get_threads() >= 1
+
+    def close(a, b, atol, rtol, what):
+        a = np.asarray(a, dtype=np.float64)[..., :-1, :]      # last row: never written
+        b = np.asarray(b, dtype=np.float64)[..., :-1, :]
+        assert np.all(np.abs(a - b) <= atol + rtol * np.abs(b)), f"{what}: max {np.max(np.abs(a - b))}"
+
+    # "thc" here is the t0 plane (see the package docstring); winds carry no window sum
+    close(thc1, g["thc1"], 0, 2e-6, "t0/1"); close(thc2, g["thc2"], 0, 2e-6, "t0/2")
+    close(ws2, g["ws2"], 1e-6, 2e-6, "ws"); close(wd2, g["wd2"], 2e-5, 2e-6, "wd")
+    # sb_con: fill values identical; triggers within the fp32 window-sum noise of the reference
+    for mine, ref in ((sb1, g["sb1"]), (sb2, g["sb2"])):
+        m, r = mine[:, :-1], ref[:, :-1]
+        fill = r > 1e19
+        assert np.array_equal(m > 1e19, fill)
+        d = np.abs(m - r)[~fill]
+        assert np.quantile(d, 0.995) < 5e-3, np.quantile(d, 0.995)   # knife-edge cells may flip at fp32
