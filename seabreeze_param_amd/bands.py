@@ -106,10 +106,17 @@ class BandRunner:
         for a in (self.z, self.sigma, self.mask):      # static fields: ghosts exchanged once
             self._fill_ghosts(a)
 
-    def upload_step_inputs(self, p, u, v, theta):
+    def upload_step_inputs(self, p, u, v, theta, local3d=False):
+        """p, u, v: the full (nz, ny, nx) fields, or with local3d=True only this band's rows
+        (nz, r1-r0, nx); theta: the full (ny, nx) field."""
         t = self.torch
-        band3 = lambda a: t.from_numpy(np.ascontiguousarray(a[:, self.r0:self.r1])).to(self.dev)
-        return dict(p=band3(p), u=band3(u), v=band3(v), theta=self._halo_field(theta))
+        if local3d:
+            band3 = lambda a: t.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        else:
+            band3 = lambda a: t.from_numpy(np.ascontiguousarray(a[:, self.r0:self.r1])).to(self.dev)
+        out = dict(p=band3(p), u=band3(u), v=band3(v), theta=self._halo_field(theta))
+        assert out["p"].shape == (self.nz, self.nyl, self.nx), out["p"].shape
+        return out
 
     # -- one model step -------------------------------------------------------------------
     def step(self, timestep: float, tn: int, s):

@@ -30,7 +30,9 @@ struct sb_ctx {
     int radius_hint = 16;
     int ncu = 256;              // compute units of the device
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd;
+    int tiles_n = 0, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
+    int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
     unsigned int *ticket = nullptr;
     void *stats = nullptr;      // 4 x double
@@ -100,32 +102,57 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st) {
     const size_t ncell = (size_t)g.nxh * g.nyh;
     const size_t nbits = (size_t)g.nyh * g.nw * sizeof(uint64_t);
     int rc;
-    if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
     const int tyrows = sb_thc_tile_rows(H);
     const int tx = (g.nx + 63) / 64, ty = (g.rows + tyrows - 1) / tyrows;
-    // per-tile flags followed by the two slow-path counters: one memset clears both
-    if ((rc = ensure(c, c->tiles, ((size_t)tx * ty + 2) * sizeof(int)))) return rc;
+    // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
+    // raises flags in this call's buffer, k_final clears the other one for the next call, so no
+    // memset sits on the critical path and the last call's values stay readable.
+    const int nflag = tx * ty + 2;
+    if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag) {
+        if ((rc = ensure(c, c->tiles, (size_t)2 * nflag * sizeof(int)))) return rc;
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemset(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int)));
+        c->tiles_n = nflag;
+        c->flag_parity = 0;
+    }
+    int *flags_now = (int *)c->tiles.p + (size_t)c->flag_parity * nflag;
+    int *flags_next = (int *)c->tiles.p + (size_t)(1 - c->flag_parity) * nflag;
     job.thc_ty = tyrows; job.thc_ntx = tx; job.thc_nty = ty;
-    job.t0 = (T *)c->t0.p;
     job.bandbits = (uint64_t *)c->bandbits.p;
     job.clsbits = (uint64_t *)c->clsbits.p;
     job.stats = (const T *)c->stats;
-    job.tile_nnmax = (int *)c->tiles.p;
-    job.counters = (int *)c->tiles.p + (size_t)tx * ty;
+    job.tile_nnmax = flags_now;
+    job.counters = flags_now + (size_t)tx * ty;
+    job.next_flags = flags_next;
+    job.next_flags_n = nflag;
+    // this call's wind speed / direction at band cells (k_wind -> k_final)
+    if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
+    if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
+    job.nws = (T *)c->nws.p;
+    job.nwd = (T *)c->nwd.p;
+    // the host-model flavour derives t0 inside k_thc; the f2py flavour returns the t0 plane
+    job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
+    // one workspace field: t0 itself (f2py flavour) or gz = (gmma*z)*sigmoid(sigma) (host-model flavour)
+    if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
+    job.t0 = (T *)c->t0.p;
     job.stamps = nullptr;
 #ifdef SB_STAMPS
     if ((rc = ensure(c, c->stamps, (size_t)tx * ty * 8 * sizeof(long long)))) return rc;
     job.stamps = (long long *)c->stamps.p;
     HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, (size_t)tx * ty * 8 * sizeof(long long), st));
 #endif
-    HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, ((size_t)tx * ty + 2) * sizeof(int), st));
-    hipEvent_t *ev = nullptr;
-    if (c->prof_calls < c->prof_max) ev = &c->prof_ev[(size_t)5 * c->prof_calls++];
-    HIPCHK(c, sb_launch_diag<T>(job, H, c->partials, c->ticket, (T *)c->stats, st, ev, c->gathered, c->ngathered,
-                                c->ncu));
+    SbLaunchCtx lc;
+    lc.stream = st;
+    lc.prof = nullptr;
+    if (c->prof_calls < c->prof_max) lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
+    lc.partials = c->partials; lc.stats = c->stats;
+    lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
+    HIPCHK(c, sb_launch_diag<T>(job, H, lc));
+    c->last_flags = flags_now;
+    c->flag_parity = 1 - c->flag_parity;
     c->last_g = g;
     c->last_tiles = tx * ty;
     c->have_last = true;
@@ -283,7 +310,7 @@ int sigmoid_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, c->ticket, (T *)c->stats, nullptr, st));
+    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, (T *)c->stats, nullptr, st));
     HIPCHK(c, sb_launch_sigmoid_apply<T>(ary, sm, (size_t)nx * ny, (const T *)c->stats, st));
     return SB_OK;
 }
@@ -308,8 +335,8 @@ int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, doubl
     if (nx < 1 || ny < 1 || halo < 0 || !sigma || !moments5) return fail(c, SB_ERR_ARG, "bad sigma_moments arguments");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const int nxh = nx + 2 * halo;
-    HIPCHK(c, sb_launch_stats<T>(sigma, nx, ny, nxh, (size_t)halo * nxh + halo, c->partials, c->ticket,
-                                 (T *)c->stats, (Moments *)moments5, st));
+    HIPCHK(c, sb_launch_stats<T>(sigma, nx, ny, nxh, (size_t)halo * nxh + halo, c->partials, (T *)c->stats,
+                                 (Moments *)moments5, st));
     return SB_OK;
 }
 
@@ -478,7 +505,7 @@ int sb_destroy(sb_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps})
+    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);
@@ -528,26 +555,29 @@ int sb_profile_begin(sb_ctx *c, int max_calls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (max_calls < 1 || max_calls > 100000) return fail(c, SB_ERR_ARG, "max_calls out of range");
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    c->prof_ev.assign((size_t)5 * max_calls, nullptr);
+    c->prof_ev.assign((size_t)SB_PROF_EVENTS * max_calls, nullptr);
     for (hipEvent_t &e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
     c->prof_calls = 0;
     c->prof_max = max_calls;
     return SB_OK;
 }
 
-int sb_profile_end(sb_ctx *c, double avg_ms[4], int *ncalls) {
+int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
     HIPCHK(c, hipDeviceSynchronize());
-    double sum[4] = {0, 0, 0, 0};
+    // consecutive event pairs bracket k_scan (+ moments merge), k_wind, k_t0, k_thc
+    static const int first[SB_PROF_KERNELS] = {0, 1, 2, 3}, last[SB_PROF_KERNELS] = {1, 2, 3, 4};
+    double sum[SB_PROF_KERNELS] = {0, 0, 0, 0};
     for (int i = 0; i < c->prof_calls; ++i)
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SB_PROF_KERNELS; ++k) {
             float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->prof_ev[(size_t)5 * i + k], c->prof_ev[(size_t)5 * i + k + 1]));
+            const hipEvent_t *e = &c->prof_ev[(size_t)SB_PROF_EVENTS * i];
+            HIPCHK(c, hipEventElapsedTime(&ms, e[first[k]], e[last[k]]));
             sum[k] += ms;
         }
     *ncalls = c->prof_calls;
-    for (int k = 0; k < 4; ++k) avg_ms[k] = c->prof_calls ? sum[k] / c->prof_calls : 0.0;
+    for (int k = 0; k < SB_PROF_KERNELS; ++k) avg_ms[k] = c->prof_calls ? sum[k] / c->prof_calls : 0.0;
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
     c->prof_calls = c->prof_max = 0;
@@ -571,7 +601,7 @@ int sb_last_counters(sb_ctx *c, long long counters[4]) {
     std::vector<int> tiles((size_t)c->last_tiles + 2);
     int cnt[2] = {0, 0};
     HIPCHK(c, hipMemcpy(bits.data(), c->bandbits.p, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(tiles.data(), c->tiles.p, tiles.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tiles.data(), c->last_flags, tiles.size() * sizeof(int), hipMemcpyDeviceToHost));
     cnt[0] = tiles[(size_t)c->last_tiles];
     cnt[1] = tiles[(size_t)c->last_tiles + 1];
     tiles.resize((size_t)c->last_tiles);

@@ -88,6 +88,10 @@ struct DiagJob {
     T *ws, *wd, *thc, *sb_con;
     T *out;                         // wrapper: (nx,ny,4) packed output, else nullptr
     // workspace
+    T *nws, *nwd;                   // (nx, ny): this call's wind speed / direction at band cells (k_wind -> k_final)
+    int *next_flags;                // the other tile-flag buffer: k_final clears it for the next call
+    int next_flags_n;
+    int t0_fly;                     // 1: k_thc derives t0 from theta,z,sigma while staging; 0: reads the t0 workspace
     T *t0;                          // (nxh, nyh)
     uint64_t *bandbits;             // nyh * nw words: interior cells with |mask| <= maxdist
     uint64_t *clsbits;              // nyh * nw words: mask >= 0 ("land side")
@@ -110,4 +114,62 @@ __host__ __device__ inline T sb_modulo(T a, T p) {
         if (r == T(0)) r = -r; else r += p;
     }
     return r;
+}
+
+// t0 = theta - (gmma*z)*sigmoid(sigma)   ref: generic/sea_breeze_diag.f90:166-167,478-480
+// At sea level (z == 0) the product is a signed zero whatever the sigmoid, so theta comes
+// back bit for bit and the exp is skipped -- most cells of a coastal tile are ocean.
+template <typename T>
+__device__ __forceinline__ T sb_t0(T theta, T z, T sigma, T sd, T r) {
+    if (z == T(0)) return theta;
+    return theta - ((T(-0.0060956) * z) * (T(1) / (T(1) + exp(-sd * (sigma - r)))));
+}
+
+// Thresholds, scaling and state update of one band cell at linear index o, given this
+// call's contrast n_thc and the wind speed/direction k_wind left in the workspace.
+// ref: generic/sea_breeze_diag.f90:235-266, seabreeze_diag_python.f90:236-280
+template <typename T>
+struct SbCellState {
+    T n_ws, n_wd, ws, wd;           // this call's wind (from k_wind) and the carried state
+};
+
+// the loads of sb_trigger_update, separable so a kernel can issue them early
+template <typename T>
+__device__ __forceinline__ SbCellState<T> sb_trigger_load(const DiagJob<T> &job, size_t o) {
+    SbCellState<T> s;
+    s.n_ws = job.nws[o]; s.n_wd = job.nwd[o]; s.ws = job.ws[o]; s.wd = job.wd[o];
+    return s;
+}
+
+template <typename T>
+__device__ __forceinline__ void sb_trigger_update(const DiagJob<T> &job, size_t o, T n_thc,
+                                                  const SbCellState<T> &st) {
+    const T n_ws = st.n_ws, n_wd = st.n_wd;
+    T ws_old = st.ws, wd_old = st.wd;
+    if (job.tn < 2) { ws_old = n_ws; wd_old = n_wd; }            // ref :235-239
+    const T thc_abs = fabs(n_thc);
+    const T mws = (ws_old + n_ws) / T(2);
+    const T dws = fabs(ws_old - n_ws);
+    const T dwd = fabs(sb_modulo<T>((wd_old - n_wd) + T(180), T(360)) - T(180));
+    T sb = T(0);
+    if (dwd < job.thr_dir && dws < job.thr_ch && mws < job.thr_wind && thc_abs > job.thr_thc) {
+        const T scale_wind = (job.thr_wind - mws) / (mws > T(1) ? mws : T(1));
+        const T scale_thc = (thc_abs - job.thr_thc) / n_thc;
+        sb = scale_thc * scale_wind;
+    }
+    job.thc[o] = n_thc;                                          // ref :262
+    if (job.flavour == SB_FLAVOUR_GENERIC) {
+        job.sb_con[o] = sb;
+        job.ws[o] = n_ws;                                        // ref :261 (every call)
+        if (job.refresh) job.wd[o] = n_wd;                       // ref :264-266
+        else if (job.tn < 2) job.wd[o] = wd_old;
+    } else {
+        const size_t pl = (size_t)job.g.nx * job.g.ny;
+        T ws_new = ws_old, wd_new = wd_old;                      // ref: seabreeze_diag_python.f90:268-280
+        if (job.refresh) { ws_new = n_ws; wd_new = n_wd; }
+        if (job.refresh || job.tn < 2) { job.ws[o] = ws_new; job.wd[o] = wd_new; }
+        job.out[o] = sb;
+        job.out[2 * pl + o] = ws_new;
+        job.out[3 * pl + o] = wd_new;
+    }
 }

@@ -1,23 +1,26 @@
 // sb_diag_kernels.hip -- the seabreeze_diag hot path as CDNA4 (gfx950) kernels.
 //
 // One call of seabreeze_diag / diag (ref: generic/sea_breeze_diag.f90:55-271,
-// python_wrapper/seabreezediag/seabreeze_diag_python.f90:49-285) is four launches on
-// one stream:
+// python_wrapper/seabreezediag/seabreeze_diag_python.f90:49-285) is four launches on one
+// stream (five for the f2py flavour):
 //
-//   k_stats  sigma -> (mean, M2, min, max) -> std, r          [HBM stream, 1 field]
-//   k_prep   t0 = theta - (gmma*z)*sigmoid(sigma); class + band bit planes; the
-//            fill value for every cell outside the coastal band   [HBM stream]
-//   k_thc    per 64x32 tile that touches the band: summed-area tables of t0 in LDS,
-//            expanding-window land/sea contrast -> thc            [LDS bound]
-//   k_wind   per band cell: level nearest target_plev in the p column, wind
-//            speed/direction, thresholds, state update -> sb_con  [HBM gather]
+//   k_scan   one pass over sigma and mask: per-workgroup moments of sigma, the band and
+//            land-side bit planes, tile flags, and the fill value for every cell outside
+//            the coastal band; k_moments_final merges the moments -> std, r   [HBM stream]
+//   k_wind   per band cell (dense lanes): level nearest target_plev in the p column, wind
+//            speed / direction                                               [HBM gather]
+//   k_t0     f2py flavour only: the t0 plane is an output there               [HBM stream]
+//   k_thc    (sb_thc_kernel.hip) per active 64 x TY tile: t0 and its summed-area tables in
+//            LDS, bisection for the window radius -> thc, then thresholds, scaling and
+//            state update -> sb_con                                           [LDS]
 //
 // Memory-bound integer/fp64 work: no MFMA anywhere.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------
-// k_stats
+// moments helpers
 // ------------------------------------------------------------------------------------
 #define STATS_NT 1024
 
@@ -35,7 +38,7 @@ __device__ __forceinline__ Moments wave_merge(Moments m) {
     return m;
 }
 
-// merge across the waves of a workgroup; the result is valid in thread 0
+// merge across the waves of a 1024-thread workgroup; the result is valid in thread 0
 __device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
     m = wave_merge(m);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -62,17 +65,56 @@ __device__ __forceinline__ void sigmoid_scalars(const Moments &m, T *__restrict_
     stats[3] = var;
 }
 
-// One workgroup per CU streams its share of sigma with 8 independent loads per thread in
-// flight.  Sums are taken about a common shift c (the first interior value), so the inner
-// loop is two adds and a multiply per element; the shifted sums become (n, mean, M2) once
-// per thread and are merged pairwise (Chan) from there on.  The last workgroup to take a
-// ticket merges the per-workgroup partials in index order, so the result does not depend
-// on arrival order.
+// Shifted sums of one thread -> (n, mean, M2)
+__device__ __forceinline__ Moments moments_from_shifted(double c, double s1, double s2, double mn, double mx,
+                                                         int cnt) {
+    Moments acc = moments_empty();
+    if (cnt > 0) {
+        acc.n = (double)cnt;
+        acc.mean = c + s1 / acc.n;
+        acc.m2 = s2 - s1 * s1 / acc.n;
+        acc.mn = mn;
+        acc.mx = mx;
+    }
+    return acc;
+}
+
+// Workgroup partial -> global partials.  The cross-workgroup merge is a kernel of its own
+// (k_moments_final): an in-kernel ticket would need an agent-scope release per workgroup,
+// and in a kernel that also writes tens of MB (k_scan's fill) every such release drains
+// the XCD's dirty L2 -- measured 20 us for 512 workgroups, against ~2 us for the boundary.
+__device__ __forceinline__ void store_partial(Moments acc, Moments *wpart, Moments *__restrict__ partials) {
+    acc = block_merge(acc, wpart);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// One workgroup merges the partials in index order (a fixed tree: the result does not
+// depend on arrival order) and publishes either the moments themselves (band-local, for
+// the multi-GPU gather) or the sigmoid scalars.
+template <typename T>
+__global__ __launch_bounds__(STATS_NT) void k_moments_final(const Moments *__restrict__ partials, int nparts,
+                                                            T *__restrict__ stats,
+                                                            Moments *__restrict__ moments_out) {
+    __shared__ Moments wpart[STATS_NT / SB_WAVE];
+    Moments m = moments_empty();
+    for (int b = threadIdx.x; b < nparts; b += STATS_NT) m = moments_merge(m, partials[b]);
+    m = block_merge(m, wpart);
+    if (threadIdx.x == 0) {
+        if (moments_out) *moments_out = m;
+        else sigmoid_scalars<T>(m, stats);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_stats: statistics of a plain 2-D field (stand-alone sigmoid; band-local moments for
+// the multi-GPU gather).  One workgroup per CU, 8 independent loads per thread in flight;
+// sums about a common shift c (first element) -> (n, mean, M2) once per thread, merged
+// pairwise (Chan) from there on.  Replaces the reference's two sequential passes
+// (ref: generic/sea_breeze_diag.f90:466-477).
+// ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, int nx, int ny, int ld,
-                                                    size_t off0, Moments *__restrict__ partials,
-                                                    unsigned int *__restrict__ ticket,
-                                                    T *__restrict__ stats, Moments *__restrict__ moments_out) {
+                                                    size_t off0, Moments *__restrict__ partials) {
     const unsigned n = (unsigned)nx * (unsigned)ny;
     const unsigned stride = gridDim.x * STATS_NT;
     const bool flat = (ld == nx);
@@ -102,50 +144,8 @@ __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, i
             }
         }
     }
-    Moments acc = moments_empty();
-    if (cnt > 0) {
-        acc.n = (double)cnt;
-        acc.mean = c + s1 / acc.n;
-        acc.m2 = s2 - s1 * s1 / acc.n;
-        acc.mn = mn;
-        acc.mx = mx;
-    }
     __shared__ Moments wpart[STATS_NT / SB_WAVE];
-    __shared__ bool is_last;
-    acc = block_merge(acc, wpart);
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x] = acc;
-        // publish: agent-scope release, drained, then the ticket
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int t = atomicAdd(ticket, 1u);
-        is_last = (t == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    // last workgroup to arrive: every thread fetches one partial, then a fixed merge tree
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    Moments m = moments_empty();
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += STATS_NT) {
-        const Moments *pp = &partials[b];
-        Moments o;
-        o.n = __builtin_nontemporal_load(&pp->n);
-        o.mean = __builtin_nontemporal_load(&pp->mean);
-        o.m2 = __builtin_nontemporal_load(&pp->m2);
-        o.mn = __builtin_nontemporal_load(&pp->mn);
-        o.mx = __builtin_nontemporal_load(&pp->mx);
-        m = moments_merge(m, o);
-    }
-    m = block_merge(m, wpart);
-    if (threadIdx.x == 0) {
-        if (moments_out) *moments_out = m;       // band-local moments for the multi-GPU gather
-        else sigmoid_scalars<T>(m, stats);
-        *ticket = 0u;                            // re-arm for the next call on this stream
-    }
+    store_partial(moments_from_shifted(c, s1, s2, mn, mx, cnt), wpart, partials);
 }
 
 // Merge the moments gathered from every latitude band (one entry per rank) and derive the
@@ -160,9 +160,7 @@ __global__ __launch_bounds__(SB_WAVE) void k_merge_moments(const Moments *__rest
     if (threadIdx.x == 0) sigmoid_scalars<T>(m, stats);
 }
 
-// ------------------------------------------------------------------------------------
-// k_sigmoid_apply: sm = 1/(1+exp(-std*(ary-r)))   ref: generic/sea_breeze_diag.f90:480
-// ------------------------------------------------------------------------------------
+// sm = 1/(1+exp(-std*(ary-r)))   ref: generic/sea_breeze_diag.f90:480
 template <typename T>
 __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary, T *__restrict__ sm,
                                                        size_t n, const T *__restrict__ stats) {
@@ -172,91 +170,242 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
 }
 
 // ------------------------------------------------------------------------------------
-// k_prep: one thread per cell of the (nxh, nyh) arrays; a wave is one aligned 64-cell
-// longitude segment, so its ballots are exactly the words of the bit planes.
+// k_scan: one persistent 1024-thread workgroup per CU streams sigma and mask.  A wave
+// owns aligned 64-cell longitude segments (four per trip, eight loads in flight), so its
+// ballots are exactly the words of the bit planes.
+//   * sigma  -> shifted sums -> one (n, mean, M2, min, max) partial per workgroup
+//   * mask   -> land-side bit  mask >= 0              ref: generic/sea_breeze_diag.f90:182,200
+//            -> band bit  !(|mask| > maxdist)         ref :174
+//            -> flag of the k_thc tile(s) the segment's band cells fall in
+//            -> fill value outside the band           ref :176 / seabreeze_diag_python.f90:173,279-280
 // ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_prep(DiagJob<T> job) {
+template <typename T, int SPT>
+__global__ __launch_bounds__(STATS_NT, 8) void k_scan(DiagJob<T> job, Moments *__restrict__ partials,
+                                                   int do_stats) {
     const Geo g = job.g;
-    const int X = blockIdx.x * 256 + threadIdx.x;
-    const int Y = blockIdx.y;
-    const bool in = X < g.nxh;
-    const T gmma = T(-0.0060956);                // ref: generic/sea_breeze_diag.f90:138
-    T m = T(0), t0v = T(0);
-    bool cls = false, band = false;
-    const int xi = X - g.h, yi = Y - g.h;        // interior coordinates
-    const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
-    if (in) {
-        const size_t idx = (size_t)Y * g.nxh + X;
-        const T sd = job.stats[0], r = job.stats[1];
-        const T sg = job.sigma[idx];
-        const T smod = T(1) / (T(1) + exp(-sd * (sg - r)));
-        t0v = job.theta[idx] - ((gmma * job.z[idx]) * smod);   // ref :167
-        job.t0[idx] = t0v;
-        m = job.mask[idx];
-        cls = (m >= T(0));                                     // ref :182, :200
-        band = interior && yi < g.rows && !(fabs(m) > job.maxdist);   // ref :174
-    }
-    const uint64_t wc = __ballot(cls);
-    const uint64_t wb = __ballot(band);
-    // raise the flag of every thc tile this segment's band cells fall in (it straddles two
-    // tile columns when the ghost width is not a multiple of 64); plain stores of 1
-    const int tA = ((X & ~63) - g.h) >> 6;
-    const uint64_t mA = __ballot(band && (xi >> 6) == tA);
-    const uint64_t mB = __ballot(band && (xi >> 6) == tA + 1);
-    if ((threadIdx.x & 63) == 0 && (X >> 6) < g.nw) {
-        job.clsbits[(size_t)Y * g.nw + (X >> 6)] = wc;
-        job.bandbits[(size_t)Y * g.nw + (X >> 6)] = wb;
-        if (wb) {
-            const int trow = (yi / job.thc_ty) * job.thc_ntx;
-            if (mA) job.tile_nnmax[trow + tA] = 1;
-            if (mB) job.tile_nnmax[trow + tA + 1] = 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NWV = STATS_NT / SB_WAVE;              // waves per workgroup; SPT segments per trip
+    const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+    // wave w of the grid takes segments w, w + W, w + 2W, ... (W = waves in the grid): every
+    // wave gets floor or ceil of nseg/W segments, and neighbouring waves read neighbouring memory
+    const unsigned nwaves = gridDim.x * NWV;
+    const size_t pl = (size_t)g.nx * g.ny;
+    const bool wrapper = job.flavour == SB_FLAVOUR_WRAPPER;
+    const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
+    double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
+    int cnt = 0;
+
+    // (row, word) of the wave's first segment and of the stride, kept wave-uniform: the
+    // segment walk then needs no division (this kernel is issue-bound, not byte-bound)
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(blockIdx.x * NWV + wv);
+    const unsigned unw = (unsigned)g.nw;
+    unsigned Yc = w0 / unw, Xc = w0 - Yc * unw;
+    const unsigned dY = nwaves / unw, dX = nwaves - dY * unw;
+    const unsigned nxh = (unsigned)g.nxh, unx = (unsigned)g.nx;
+
+    for (unsigned s0 = w0; s0 < nseg; s0 += SPT * nwaves) {
+        T sg[SPT], mk[SPT], wsv[SPT], wdv[SPT];
+        unsigned Yq[SPT], Wq[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const unsigned seg = s0 + q * nwaves;
+            Yq[q] = Yc;
+            Wq[q] = Xc;
+            const int X = (int)(Xc * 64u) + lane;
+            const int xi = X - g.h, yi = (int)Yc - g.h;
+            const bool in = seg < nseg && X < g.nxh;
+            const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
+            sg[q] = T(0); mk[q] = T(0); wsv[q] = T(0); wdv[q] = T(0);
+            if (in) {
+                const unsigned idx = Yc * nxh + (unsigned)X;
+                mk[q] = job.mask[idx];
+                if (do_stats && interior) sg[q] = job.sigma[idx];
+            }
+            if (wrapper && interior && yi < g.rows) {
+                const unsigned o = (unsigned)yi * unx + (unsigned)xi;
+                wsv[q] = job.ws[o];
+                wdv[q] = job.wd[o];
+            }
+            Yc += dY; Xc += dX;
+            if (Xc >= unw) { Xc -= unw; Yc += 1; }
+        }
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const unsigned seg = s0 + q * nwaves;
+            if (seg >= nseg) break;                              // wave-uniform
+            const int X = (int)(Wq[q] * 64u) + lane, xi = X - g.h, yi = (int)Yq[q] - g.h;
+            const bool in = X < g.nxh;
+            const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
+            if (do_stats && interior) {
+                const double x = (double)sg[q], d = x - c;
+                s1 += d;
+                s2 = __builtin_fma(d, d, s2);
+                mn = fmin(mn, x);
+                mx = fmax(mx, x);
+                ++cnt;
+            }
+            const bool cls = in && (mk[q] >= T(0));
+            const bool band = interior && yi < g.rows && !(fabs(mk[q]) > job.maxdist);
+            const uint64_t wc = __ballot(cls);
+            const uint64_t wb = __ballot(band);
+            if (lane == 0) {
+                job.clsbits[seg] = wc;
+                job.bandbits[seg] = wb;
+            }
+            if (wb) {                                            // wave-uniform
+                // the segment straddles two tile columns when the ghost width is not a multiple of 64
+                const int tA = ((int)(Wq[q] * 64u) - g.h) >> 6;
+                const uint64_t mB = __ballot(band && (xi >> 6) != tA);
+                if (lane == 0) {
+                    const int trow = (yi / job.thc_ty) * job.thc_ntx;
+                    if (wb & ~mB) job.tile_nnmax[trow + tA] = 1;     // plain stores of 1: benign duplicates
+                    if (mB) job.tile_nnmax[trow + tA + 1] = 1;
+                }
+            }
+            if (interior && yi < g.rows && !band) {
+                const unsigned o = (unsigned)yi * unx + (unsigned)xi;
+                if (!wrapper) job.sb_con[o] = job.fill;
+                else {
+                    job.out[o] = job.fill;
+                    job.out[2 * pl + o] = wsv[q];
+                    job.out[3 * pl + o] = wdv[q];
+                }
+            }
         }
     }
-    if (interior && yi < g.rows) {
-        const size_t o = (size_t)yi * g.nx + xi;
-        if (job.flavour == SB_FLAVOUR_GENERIC) {
-            if (!band) job.sb_con[o] = job.fill;               // ref :176
-        } else {
-            // packed output planes, ref: seabreeze_diag_python.f90:277-280
-            const size_t pl = (size_t)g.nx * g.ny;
-            job.out[pl + o] = t0v;
-            if (!band) {
-                job.out[o] = job.fill;                         // 2.0E20, ref :173
-                job.out[2 * pl + o] = job.ws[o];
-                job.out[3 * pl + o] = job.wd[o];
+    if (!do_stats) return;
+    __shared__ Moments wpart[STATS_NT / SB_WAVE];
+    store_partial(moments_from_shifted(c, s1, s2, mn, mx, cnt), wpart, partials);
+}
+
+// ------------------------------------------------------------------------------------
+// k_t0: t0 = theta - (gmma*z)*sigmoid(sigma) for every cell   ref: generic/...:167
+// Used by the f2py flavour, whose t0 plane is an output (seabreeze_diag_python.f90:278);
+// the host-model flavour derives t0 inside k_thc while staging instead.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_t0(DiagJob<T> job) {
+    const Geo g = job.g;
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= g.nxh) return;
+    const size_t idx = (size_t)Y * g.nxh + X;
+    const T sd = job.stats[0], r = job.stats[1];
+    const T t0v = sb_t0<T>(job.theta[idx], job.z[idx], job.sigma[idx], sd, r);
+    job.t0[idx] = t0v;
+    const int xi = X - g.h, yi = Y - g.h;
+    if (job.out && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.rows)
+        job.out[(size_t)g.nx * g.ny + (size_t)yi * g.nx + xi] = t0v;
+}
+
+// ------------------------------------------------------------------------------------
+// k_gz: gz = (gmma*z)*sigmoid(sigma), the static part of t0 = theta - gz (ref: generic/
+// sea_breeze_diag.f90:166-167), for the host-model flavour.  Only the k_thc tiles within
+// the LDS halo of an active tile are filled (about 4 in 10): one workgroup per tile checks
+// the flags of its neighbourhood first.  With ghost cells (multi-GPU bands) every cell is
+// filled.  k_thc then stages theta - gz, with no exp in its (issue-bound) staging loop.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T sb_gz(T z, T sigma, T sd, T r) {
+    const T gzm = T(-0.0060956) * z;
+    if (z == T(0)) return gzm;                   // a signed zero whatever the sigmoid: skip the exp
+    return gzm * (T(1) / (T(1) + exp(-sd * (sigma - r))));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gz(DiagJob<T> job, int dxt, int dyt) {
+    const Geo g = job.g;
+    const int tx = blockIdx.x, ty = blockIdx.y, TY = job.thc_ty;
+    const T sd = job.stats[0], r = job.stats[1];
+    if (g.h > 0) {
+        // ghost-celled band: plain sweep of the whole (nxh, nyh) frame, 64 x TY cells per workgroup
+        for (int i = threadIdx.x; i < 64 * TY; i += 256) {
+            const int X = tx * 64 + (i & 63), Y = ty * TY + (i >> 6);
+            if (X < g.nxh && Y < g.nyh) {
+                const size_t idx = (size_t)Y * g.nxh + X;
+                job.t0[idx] = sb_gz<T>(job.z[idx], job.sigma[idx], sd, r);
             }
+        }
+        return;
+    }
+    // is any tile within (dxt, dyt) tiles of this one active?  (longitude wraps, latitude does not)
+    int any = 0;
+    const int nnb = (2 * dxt + 1) * (2 * dyt + 1);
+    for (int i = threadIdx.x; i < nnb; i += 256) {
+        const int ddx = i % (2 * dxt + 1) - dxt, ddy = i / (2 * dxt + 1) - dyt;
+        const int yy = ty + ddy;
+        int xx = (tx + ddx) % job.thc_ntx;
+        if (xx < 0) xx += job.thc_ntx;
+        if (yy >= 0 && yy < job.thc_nty && job.tile_nnmax[yy * job.thc_ntx + xx] != 0) any = 1;
+    }
+    if (!__syncthreads_or(any)) return;
+    for (int i = threadIdx.x; i < 64 * TY; i += 256) {
+        const int x = tx * 64 + (i & 63), y = ty * TY + (i >> 6);
+        if (x < g.nx && y < g.ny) {
+            const size_t idx = (size_t)y * g.nx + x;
+            job.t0[idx] = sb_gz<T>(job.z[idx], job.sigma[idx], sd, r);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------
-// k_wind: one thread per interior cell, a wave per 64-cell row segment; waves whose
-// band word is empty leave at once, so HBM traffic is the band cells' p columns only.
+// Dense band-cell enumeration inside a workgroup: the workgroup covers 256 consecutive
+// longitudes of one latitude row; the band cells among them are compacted (ballot +
+// popcount prefix) so that thread i owns the i-th band cell.  Waves are full however
+// ragged the band is, surplus waves leave, and consecutive lanes still touch consecutive
+// longitudes inside a run.  Returns the number of band cells; s_x[i] is their longitude.
 // ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_wind(DiagJob<T> job) {
+#define ROW_NT 256
+
+__device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ bandbits, const Geo &g, int y,
+                                                unsigned short *s_x, int *s_wcnt) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x = blockIdx.x * ROW_NT + tid;
+    bool band = false;
+    if (x < g.nx) band = sb_bit(bandbits, g.nw, x + g.h, y + g.h) != 0;
+    const uint64_t bm = __ballot(band);
+    if (lane == 0) s_wcnt[wv] = __popcll(bm);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < ROW_NT / SB_WAVE; ++w) {
+        const int cw = s_wcnt[w];
+        before += (w < wv) ? cw : 0;
+        total += cw;
+    }
+    if (total == 0) return 0;
+    if (band) s_x[before + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+    __syncthreads();
+    return total;
+}
+
+// ------------------------------------------------------------------------------------
+// k_wind: level nearest the target pressure + wind speed/direction for every band cell.
+// Band cells walk their p column (nz planes, stride nx*ny) with UN independent
+// non-temporal loads in flight and keep the first minimum of |p - target|
+// ref: generic/sea_breeze_diag.f90:223-227, seabreeze_diag_python.f90:228-233 (1-D p: one
+// level for all cells).
+// ------------------------------------------------------------------------------------
+template <typename T, int UN>
+__global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job) {
+    __shared__ unsigned short s_x[ROW_NT];
+    __shared__ int s_wcnt[ROW_NT / SB_WAVE];
     const Geo g = job.g;
-    const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= g.nx) return;
-    if (!sb_bit(job.bandbits, g.nw, x + g.h, y + g.h)) return;
+    // clear the other tile-flag buffer for the next call (this call's is read by k_thc)
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    for (int i = bid * ROW_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * gridDim.y * ROW_NT)
+        job.next_flags[i] = 0;
+    const int total = block_band_cells(job.bandbits, g, y, s_x, s_wcnt);
+    if ((int)threadIdx.x >= total) return;
+    const int x = blockIdx.x * ROW_NT + s_x[threadIdx.x];
     const size_t pl = (size_t)g.nx * g.ny;
     const size_t o = (size_t)y * g.nx + x;
     const int nz = job.nz;
-
-    // level nearest the target pressure: first minimum of |p - target|
-    // ref: generic/sea_breeze_diag.f90:223 (per column), seabreeze_diag_python.f90:228 (1-D p)
     int lev = 0;
     if (job.flavour == SB_FLAVOUR_GENERIC) {
-        // 14 independent streaming loads in flight per lane (4 trips for the 56-level stub
-        // layout, ref: generic/get_all_fields_mod.f90:9); each level is a separate plane so
-        // a wave reads one contiguous 64-cell segment per level.  Non-temporal: the column
-        // is read once per call.
         const T *pc = job.p + o;
         T best = fabs(__builtin_nontemporal_load(pc) - job.target_plev);
         int k = 1;
-        constexpr int UN = 14;
         for (; k + UN <= nz; k += UN) {
             T d[UN];
 #pragma unroll
@@ -280,58 +429,23 @@ __global__ __launch_bounds__(256) void k_wind(DiagJob<T> job) {
     }
     const T uu = job.u[(size_t)lev * pl + o];
     const T vv = job.v[(size_t)lev * pl + o];
-    const T rad2deg = T(57.2957);                               // ref :128 (sic)
-    const T n_ws = sqrt(uu * uu + vv * vv);                     // ref :225
-    const T n_wd = atan2(-uu, -vv) * rad2deg;                   // ref :227
-    const T n_thc = job.thc[o];                                 // written by k_thc
-    T ws_old = job.ws[o], wd_old = job.wd[o];
-    if (job.tn < 2) { ws_old = n_ws; wd_old = n_wd; }          // ref :235-239
-    // ref :242-259
-    const T thc_abs = fabs(n_thc);
-    const T mws = (ws_old + n_ws) / T(2);
-    const T dws = fabs(ws_old - n_ws);
-    const T dwd = fabs(sb_modulo<T>((wd_old - n_wd) + T(180), T(360)) - T(180));
-    T sb = T(0);
-    if (dwd < job.thr_dir && dws < job.thr_ch && mws < job.thr_wind && thc_abs > job.thr_thc) {
-        const T scale_wind = (job.thr_wind - mws) / (mws > T(1) ? mws : T(1));
-        const T scale_thc = (thc_abs - job.thr_thc) / n_thc;
-        sb = scale_thc * scale_wind;
-    }
-    if (job.flavour == SB_FLAVOUR_GENERIC) {
-        job.sb_con[o] = sb;
-        job.ws[o] = n_ws;                                       // ref :261 (every call)
-        if (job.refresh) job.wd[o] = n_wd;                      // ref :264-266
-        else if (job.tn < 2) job.wd[o] = wd_old;
-    } else {
-        // ref: seabreeze_diag_python.f90:268-280
-        T ws_new = ws_old, wd_new = wd_old;
-        if (job.refresh) { ws_new = n_ws; wd_new = n_wd; }
-        if (job.refresh || job.tn < 2) { job.ws[o] = ws_new; job.wd[o] = wd_new; }
-        job.out[o] = sb;
-        job.out[2 * pl + o] = ws_new;
-        job.out[3 * pl + o] = wd_new;
-    }
+    job.nws[o] = sqrt(uu * uu + vv * vv);                        // ref :225
+    job.nwd[o] = atan2(-uu, -vv) * T(57.2957);                   // ref :227, rad2deg (sic) :128
 }
 
 // ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 template <typename T>
-hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials,
-                           unsigned int *ticket, T *stats, Moments *moments_out, hipStream_t st) {
+hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials, T *stats,
+                           Moments *moments_out, hipStream_t st) {
     // one workgroup per CU, fewer when the field is small (8 elements per thread per trip)
     const size_t n = (size_t)nx * ny;
     int nblk = (int)((n + (size_t)STATS_NT * 8 - 1) / ((size_t)STATS_NT * 8));
     if (nblk < 1) nblk = 1;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(k_stats<T>, dim3(nblk), dim3(STATS_NT), 0, st, ary, nx, ny, ld, off0, partials, ticket,
-                       stats, moments_out);
-    return hipGetLastError();
-}
-
-template <typename T>
-hipError_t sb_launch_merge_moments(const Moments *parts, int nparts, T *stats, hipStream_t st) {
-    hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, parts, nparts, stats);
+    hipLaunchKernelGGL(k_stats<T>, dim3(nblk), dim3(STATS_NT), 0, st, ary, nx, ny, ld, off0, partials);
+    hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, partials, nblk, stats, moments_out);
     return hipGetLastError();
 }
 
@@ -344,33 +458,60 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
 }
 
 template <typename T>
-hipError_t sb_launch_diag(const DiagJob<T> &job, int H, Moments *partials, unsigned int *ticket, T *stats,
-                          hipStream_t st, hipEvent_t *ev, const Moments *gathered, int ngathered, int ncu) {
+hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     const Geo &g = job.g;
+    hipStream_t st = lc.stream;
+    hipEvent_t *ev = lc.prof;
+    static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 7;   // tuning knob (diagnostic)
+    // ---- k_scan (+ merge of the statistics) ---------------------------------------------
     if (ev) (void)hipEventRecord(ev[0], st);
-    // sigmoid statistics: over the interior of sigma, or merged from the bands' gathered moments
-    hipError_t e = gathered ? sb_launch_merge_moments<T>(gathered, ngathered, stats, st)
-                            : sb_launch_stats<T>(job.sigma, g.nx, g.ny, g.nxh, (size_t)g.h * g.nxh + g.h, partials,
-                                                 ticket, stats, nullptr, st);
-    if (e != hipSuccess) return e;
+    {
+        const bool gathered = lc.gathered != nullptr;
+        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+        int nblk = (int)((nseg + 79) / 80);                      // 16 waves x 5 segments per trip
+        if (nblk < 1) nblk = 1;
+        if (nblk > 2 * lc.ncu) nblk = 2 * lc.ncu;                // two workgroups per CU: every wave slot busy
+        static const int spt = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 3;   // tuning knob (diagnostic)
+        if (spt <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
+        else if (spt <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
+        else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
+        if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
+                                         (T *)lc.stats);
+        else hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk,
+                                (T *)lc.stats, (Moments *)nullptr);
+    }
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_prep<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+    // ---- k_wind --------------------------------------------------------------------------
+    {
+        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
+        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4>), wg, wb, 0, st, job);
+        else if (un <= 7) hipLaunchKernelGGL((k_wind<T, 7>), wg, wb, 0, st, job);
+        else hipLaunchKernelGGL((k_wind<T, 14>), wg, wb, 0, st, job);
+    }
     if (ev) (void)hipEventRecord(ev[2], st);
-    e = sb_launch_thc<T>(job, H, ncu, st);
-    if (e != hipSuccess) return e;
+    // ---- k_t0 (f2py flavour: t0 everywhere) / k_gz (host-model flavour: gz near the band) ------
+    if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+    else {
+        const int TY = job.thc_ty;
+        // tiles to look at around a tile: the halo H in tile units; one more column at the
+        // longitude seam when the last tile column is narrower than a tile
+        const int dyt = (H + TY - 1) / TY, dxt = 1 + ((g.nx & 63) ? 1 : 0);
+        const dim3 gg = g.h > 0 ? dim3((g.nxh + 63) / 64, (g.nyh + TY - 1) / TY) : dim3(job.thc_ntx, (g.ny + TY - 1) / TY);
+        hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
+    }
     if (ev) (void)hipEventRecord(ev[3], st);
-    hipLaunchKernelGGL(k_wind<T>, dim3((g.nx + 255) / 256, g.rows), dim3(256), 0, st, job);
+    // ---- k_thc: contrast + thresholds + state update ---------------------------------------
+    hipError_t e = sb_launch_thc<T>(job, H, lc.ncu, st);
+    if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[4], st);
     return hipGetLastError();
 }
 
-template hipError_t sb_launch_stats<float>(const float *, int, int, int, size_t, Moments *, unsigned int *, float *,
-                                           Moments *, hipStream_t);
-template hipError_t sb_launch_stats<double>(const double *, int, int, int, size_t, Moments *, unsigned int *,
-                                            double *, Moments *, hipStream_t);
+template hipError_t sb_launch_stats<float>(const float *, int, int, int, size_t, Moments *, float *, Moments *,
+                                           hipStream_t);
+template hipError_t sb_launch_stats<double>(const double *, int, int, int, size_t, Moments *, double *, Moments *,
+                                            hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<float>(const float *, float *, size_t, const float *, hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<double>(const double *, double *, size_t, const double *, hipStream_t);
-template hipError_t sb_launch_diag<float>(const DiagJob<float> &, int, Moments *, unsigned int *, float *,
-                                          hipStream_t, hipEvent_t *, const Moments *, int, int);
-template hipError_t sb_launch_diag<double>(const DiagJob<double> &, int, Moments *, unsigned int *, double *,
-                                           hipStream_t, hipEvent_t *, const Moments *, int, int);
+template hipError_t sb_launch_diag<float>(const DiagJob<float> &, int, const SbLaunchCtx &);
+template hipError_t sb_launch_diag<double>(const DiagJob<double> &, int, const SbLaunchCtx &);

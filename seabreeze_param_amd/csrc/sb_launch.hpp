@@ -5,17 +5,27 @@
 #define SB_STATS_MAX_BLOCKS 2048
 #define SB_MAX_LDS_HALO 24          // largest LDS halo k_thc is instantiated for
 #define SB_DIST_TY 4                 // rows per k_dist tile
+#define SB_PROF_EVENTS 5            // events one profiled diag call records
+#define SB_PROF_KERNELS 4           // k_scan, k_wind, k_t0, k_thc
+
+// Everything of the context a diag launch needs besides the job itself.
+struct SbLaunchCtx {
+    hipStream_t stream;             // every kernel of the call is enqueued here
+    hipEvent_t *prof;               // SB_PROF_EVENTS timing events of this call, or nullptr
+    Moments *partials;              // per-workgroup reduction partials
+    void *stats;                    // sigmoid scalars (4 x T)
+    const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
+    int ngathered;
+    int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
+};
 
 template <typename T>
-hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials,
-                           unsigned int *ticket, T *stats, Moments *moments_out, hipStream_t st);
+hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials, T *stats,
+                           Moments *moments_out, hipStream_t st);   // moments_out: publish moments, not scalars
 template <typename T>
 hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats, hipStream_t st);
 template <typename T>
-hipError_t sb_launch_diag(const DiagJob<T> &job, int H, Moments *partials, unsigned int *ticket, T *stats,
-                          hipStream_t st, hipEvent_t *ev,    // ev: 5 events bracketing the 4 kernels, or nullptr
-                          const Moments *gathered, int ngathered,    // non-null: merge these instead of scanning sigma
-                          int ncu);                                  // compute units (k_thc runs one workgroup per CU)
+hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
 int sb_thc_tile_rows(int H);                                         // k_thc tiles are 64 x this many cells
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st);

@@ -33,6 +33,13 @@
 // both classes is the reference's final nn.  cap bounds the radius: the reference loop has
 // none and never returns on a one-class grid (SURVEY.md §7 "Hard parts").
 // ------------------------------------------------------------------------------------
+// t0 of one cell of the ghost-celled frame: from the workspace (f2py flavour) or derived on the spot
+template <typename T>
+__device__ __forceinline__ T cell_t0(const DiagJob<T> &job, size_t idx) {
+    if (!job.t0_fly) return job.t0[idx];
+    return sb_t0<T>(job.theta[idx], job.z[idx], job.sigma[idx], job.stats[0], job.stats[1]);
+}
+
 template <typename T>
 __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &nn_used, bool &one_class) {
     const Geo g = job.g;
@@ -59,18 +66,18 @@ __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &
     nn_used = nn;
     one_class = !found;
     sb_map_cell(g, x, y, X, Y);
-    const double c0 = (double)job.t0[(size_t)Y * g.nxh + X];
+    const double c0 = (double)cell_t0(job, (size_t)Y * g.nxh + X);
     double sl = 0.0, ss = 0.0, nl = 0.0, ns = 0.0;
     for (int yy = y - nn; yy <= y + nn; ++yy)
         for (int xx = x - nn; xx <= x + nn; ++xx) {
             if (!sb_map_cell(g, xx, yy, X, Y)) continue;
-            const double d = (double)job.t0[(size_t)Y * g.nxh + X] - c0;
+            const double d = (double)cell_t0(job, (size_t)Y * g.nxh + X) - c0;
             if (sb_bit(job.clsbits, g.nw, X, Y)) { sl += d; nl += 1.0; } else { ss += d; ns += 1.0; }
         }
     return (T)(sl / nl - ss / ns);               // 0/0 -> NaN when a class is missing
 }
 
-template <typename T, int TY, int H>
+template <typename T, int TY, int H, bool FLY>
 __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     constexpr int TX = 64, NT = THC_NT;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
@@ -144,73 +151,93 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
                 cw[q] = job.clsbits[wi];
             }
         }
+        // t0 of one cell: read from the workspace (f2py flavour, where the t0 plane is an output),
+        // or formed here as theta - gz with gz = (gmma*z)*sigmoid(sigma) (ref: generic/
+        // sea_breeze_diag.f90:167) left by k_gz in the same workspace for the tiles that need it
         int X, Y;
         sb_map_cell(g, x0, y0, X, Y);
-        const T c0raw = job.t0[(size_t)Y * g.nxh + X];
-        T dv[RPW * NCH];
-        uint64_t lw[RPW * NCH];
-        int xc[RPW * NCH];
+        const size_t i00 = (size_t)Y * g.nxh + X;
+        T c_th = T(0), c_gz = T(0), c_t0 = T(0);
+        if constexpr (FLY) { c_th = job.theta[i00]; c_gz = job.t0[i00]; }
+        else c_t0 = job.t0[i00];
+        double c0 = 0.0;
+        unsigned mine = 0;
+        // rows are staged RB at a time: all their loads are issued before any result is used
+        constexpr int RB = RPW;
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) {
-            const int r = wv + ri * NWV;
-            const int ys = y0 - H + r;
-            int Yr;
-            bool rowok = r < HT;
-            if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = rowok && (Yr >= 0 && Yr < g.nyh); }
-            else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+        for (int rb = 0; rb < RPW; rb += RB) {
+            T dv[RB * NCH], zv[FLY ? RB * NCH : 1];
+            uint64_t lw[RB * NCH];
+            int xc[RB * NCH];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int c = ch * SB_WAVE + lane;
-                const int xs = x0 - H + c;
-                bool ok = rowok && c < W;
-                int Xc = 0;
-                if (fastx) {
-                    if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
-                    else if (g.bnd == BND_WRAPPER) {
-                        int m = xs + 1;
-                        m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
-                        Xc = (m < 1 ? 1 : m) - 1;
-                    } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
-                } else {
-                    int Yd;
-                    ok = ok && sb_map_cell(g, xs, ys, Xc, Yd);
-                }
-                const int k = ri * NCH + ch;
-                xc[k] = ok ? Xc : -1;
-                dv[k] = T(0);
-                lw[k] = 0;
-                if (ok) {
-                    dv[k] = job.t0[(size_t)Yr * g.nxh + Xc];
-                    lw[k] = job.clsbits[(size_t)Yr * g.nw + (Xc >> 6)];
+            for (int rj = 0; rj < RB; ++rj) {
+                const int ri = rb + rj;
+                const int r = wv + ri * NWV;
+                const int ys = y0 - H + r;
+                int Yr;
+                bool rowok = ri < RPW && r < HT;
+                if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = rowok && (Yr >= 0 && Yr < g.nyh); }
+                else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int c = ch * SB_WAVE + lane;
+                    const int xs = x0 - H + c;
+                    bool ok = rowok && c < W;
+                    int Xc = 0;
+                    if (fastx) {
+                        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
+                        else if (g.bnd == BND_WRAPPER) {
+                            int m = xs + 1;
+                            m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
+                            Xc = (m < 1 ? 1 : m) - 1;
+                        } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
+                    } else {
+                        int Yd;
+                        ok = ok && sb_map_cell(g, xs, ys, Xc, Yd);
+                    }
+                    const int k = rj * NCH + ch;
+                    xc[k] = ok ? Xc : -1;
+                    dv[k] = T(0);
+                    lw[k] = 0;
+                    if constexpr (FLY) zv[k] = T(0);
+                    if (ok) {
+                        const size_t ii = (size_t)Yr * g.nxh + Xc;
+                        if constexpr (FLY) { dv[k] = job.theta[ii]; zv[k] = job.t0[ii]; }
+                        else dv[k] = job.t0[ii];
+                        lw[k] = job.clsbits[(size_t)Yr * g.nw + (Xc >> 6)];
+                    }
                 }
             }
-        }
-        const double c0 = (double)c0raw;
-        unsigned mine = 0;
+            if (rb == 0) {
+                if constexpr (FLY) c_t0 = c_th - c_gz;
+                c0 = (double)c_t0;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) mine |= (unsigned)((bw[q] >> ((x0 + lx + g.h) & 63)) & 1ull) << q;
-
-        // ---- into LDS; the land-side count is prefixed along the row on the way in with a
-        // ballot + popcount, so only the two fp64 tables need a longitude scan ----------------
+                for (int q = 0; q < CPT; ++q) mine |= (unsigned)((bw[q] >> ((x0 + lx + g.h) & 63)) & 1ull) << q;
+            }
+            // ---- into LDS; the land-side count is prefixed along the row on the way in with a
+            // ballot + popcount, so only the two fp64 tables need a longitude scan ------------
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) {
-            const int r = wv + ri * NWV;
-            unsigned carryC = 0;
+            for (int rj = 0; rj < RB; ++rj) {
+                const int r = wv + (rb + rj) * NWV;
+                unsigned carryC = 0;
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int k = ri * NCH + ch;
-                const int c = ch * SB_WAVE + lane;
-                const bool ok = xc[k] >= 0;
-                const int land = ok ? (int)((lw[k] >> (xc[k] & 63)) & 1ull) : 0;
-                const double d = ok ? (double)dv[k] - c0 : 0.0;
-                const uint64_t lm = __ballot(land);
-                const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
-                carryC += (unsigned)__popcll(lm);
-                if (r < HT && c < W) {
-                    const int o = (r + 1) * P + c + 1;
-                    sA[o] = d;
-                    sL[o] = land ? d : 0.0;
-                    sC[o] = (unsigned short)cn;
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = rj * NCH + ch;
+                    const int c = ch * SB_WAVE + lane;
+                    const bool ok = xc[k] >= 0;
+                    const int land = ok ? (int)((lw[k] >> (xc[k] & 63)) & 1ull) : 0;
+                    T t0v = dv[k];
+                    if constexpr (FLY) t0v = dv[k] - zv[k];
+                    const double d = ok ? (double)t0v - c0 : 0.0;
+                    const uint64_t lm = __ballot(land);
+                    const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
+                    carryC += (unsigned)__popcll(lm);
+                    if (rb + rj < RPW && r < HT && c < W) {
+                        const int o = (r + 1) * P + c + 1;
+                        sA[o] = d;
+                        sL[o] = land ? d : 0.0;
+                        sC[o] = (unsigned short)cn;
+                    }
                 }
             }
         }
@@ -233,6 +260,14 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
         }
         __syncthreads();
         SB_STAMP(2);
+        // the state / wind loads of the final update: issued now, they land under the scan
+        SbCellState<T> cst[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            cst[q] = SbCellState<T>{T(0), T(0), T(0), T(0)};
+            if ((mine >> q) & 1u)
+                cst[q] = sb_trigger_load<T>(job, (size_t)(y0 + ly0 + q * (NT / TX)) * g.nx + (x0 + lx));
+        }
         // ---- prefix along latitude: one task per (table, column), batches of 16 rows ------
         for (int task = tid; task < 3 * W; task += NT) {
             const int a = task / W, c = task - a * W + 1;
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
             }
             nnmax = max(nnmax, nn);
             const T mul = ((cw[q] >> ((x + g.h) & 63)) & 1ull) ? T(1) : T(-1);        // ref :182-186
-            job.thc[(size_t)y * g.nx + x] = mul * contrast;                           // ref :216, :262
+            sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);  // ref :216, :235-266
         }
         // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters)
 #pragma unroll
@@ -347,7 +382,8 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
 
 template <typename T, int TY, int H>
 static void launch_thc(const DiagJob<T> &job, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((k_thc<T, TY, H>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+    if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+    else hipLaunchKernelGGL((k_thc<T, TY, H, false>), dim3(nblocks), dim3(THC_NT), 0, st, job);
 }
 
 int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }

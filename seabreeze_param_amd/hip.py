@@ -105,11 +105,13 @@ class Context:
         self._chk(self.lib.sb_profile_begin(self.h, C.c_int(max_calls)), "sb_profile_begin")
 
     def profile_end(self):
-        """-> ({'k_stats': ms, 'k_prep': ms, 'k_thc': ms, 'k_wind': ms}, ncalls), HIP-event averages."""
+        """-> ({'k_scan': ms, 'k_wind': ms, 'k_t0': ms, 'k_thc': ms}, ncalls): HIP-event averages of the
+        launches of one diag call, in launch order (k_scan includes the small moments merge; k_t0 is
+        empty for the host-model flavour)."""
         ms = (C.c_double * 4)()
         n = C.c_int(0)
         self._chk(self.lib.sb_profile_end(self.h, ms, C.byref(n)), "sb_profile_end")
-        return dict(k_stats=ms[0], k_prep=ms[1], k_thc=ms[2], k_wind=ms[3]), n.value
+        return dict(k_scan=ms[0], k_wind=ms[1], k_t0=ms[2], k_thc=ms[3]), n.value
 
     # ------------------------------------------------------------------ host-pointer API
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,

@@ -38,15 +38,27 @@ def _mix(x: np.ndarray) -> np.ndarray:
     return x
 
 
-def hash_uniform(shape, stream: int, seed: int = SEED) -> np.ndarray:
-    """U[0,1) on a regular index grid: 24-bit dyadic rationals (exact in fp32)."""
-    n = int(np.prod(shape))
+def hash_uniform(shape, stream: int, seed: int = SEED, rows=None) -> np.ndarray:
+    """U[0,1) on a regular index grid: 24-bit dyadic rationals (exact in fp32).
+
+    `rows=(r0, r1)` returns only rows r0:r1 of the second-to-last axis (a latitude band) of
+    the field `shape` describes, with the same values the full field has there."""
     with np.errstate(over="ignore"):
-        ctr = np.arange(n, dtype=np.uint64)
+        if rows is None:
+            ctr = np.arange(int(np.prod(shape)), dtype=np.uint64)
+            out_shape = tuple(shape)
+        else:
+            r0, r1 = rows
+            ny, nx = shape[-2], shape[-1]
+            lead = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            plane = (np.arange(r0, r1, dtype=np.uint64)[:, None] * np.uint64(nx)
+                     + np.arange(nx, dtype=np.uint64)[None, :])
+            ctr = (np.arange(lead, dtype=np.uint64)[:, None, None] * np.uint64(ny * nx) + plane[None]).ravel()
+            out_shape = tuple(shape[:-2]) + (r1 - r0, nx)
         key = _mix(np.array([np.uint64(seed) * _G + np.uint64(stream)], dtype=np.uint64))[0]
         bits = _mix(ctr * _G + key)
     u = (bits >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
-    return u.reshape(shape)
+    return u.reshape(out_shape)
 
 
 def hash_normal(shape, stream: int, seed: int = SEED) -> np.ndarray:
@@ -106,8 +118,9 @@ def pressure_1d(nz: int, dtype=np.float64) -> np.ndarray:
     return np.ascontiguousarray(101325.0 * sigma_levels(nz), dtype=dtype)
 
 
-def pressure_3d(st: StaticFields, nz: int, dtype=np.float64) -> np.ndarray:
-    ps = 101325.0 - 11.5 * st.z.astype(np.float64)
+def pressure_3d(st: StaticFields, nz: int, dtype=np.float64, rows=None) -> np.ndarray:
+    r0, r1 = rows if rows is not None else (0, st.ny)
+    ps = 101325.0 - 11.5 * st.z[r0:r1].astype(np.float64)
     return np.ascontiguousarray(sigma_levels(nz)[:, None, None] * ps[None], dtype=dtype)
 
 
@@ -120,13 +133,15 @@ def theta_step(st: StaticFields, t: int, dtype=np.float64, seed: int = SEED) -> 
     return np.ascontiguousarray(th, dtype=dtype)
 
 
-def wind_step(st: StaticFields, nz: int, t: int, dtype=np.float64, seed: int = SEED):
-    """u, v of shape (nz, ny, nx): speed straddles 11 m/s, direction drifts with t."""
+def wind_step(st: StaticFields, nz: int, t: int, dtype=np.float64, seed: int = SEED, rows=None):
+    """u, v of shape (nz, ny, nx): speed straddles 11 m/s, direction drifts with t.
+    `rows=(r0, r1)` generates only that latitude band, identical to the full field's rows."""
+    r0, r1 = rows if rows is not None else (0, st.ny)
     lam = np.deg2rad(st.lon.astype(np.float64))[None, None, :]
-    phi = np.deg2rad(st.lat.astype(np.float64))[None, :, None]
+    phi = np.deg2rad(st.lat[r0:r1].astype(np.float64))[None, :, None]
     lev = np.arange(nz, dtype=np.float64)[:, None, None]
     psi = 2.0 * lam + 3.0 * phi + 0.11 * lev + 0.02 * t
     shape = (nz, st.ny, st.nx)
-    u = 7.0 * np.cos(psi) + 4.0 * (2.0 * hash_uniform(shape, 1000 + 2 * t, seed) - 1.0)
-    v = 7.0 * np.sin(psi) + 4.0 * (2.0 * hash_uniform(shape, 1001 + 2 * t, seed) - 1.0)
+    u = 7.0 * np.cos(psi) + 4.0 * (2.0 * hash_uniform(shape, 1000 + 2 * t, seed, rows=rows) - 1.0)
+    v = 7.0 * np.sin(psi) + 4.0 * (2.0 * hash_uniform(shape, 1001 + 2 * t, seed, rows=rows) - 1.0)
     return np.ascontiguousarray(u, dtype=dtype), np.ascontiguousarray(v, dtype=dtype)

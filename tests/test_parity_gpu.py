@@ -231,6 +231,33 @@ def test_search_radius_beyond_lds_halo(hipctx, oracles):
     _assert_close64(sh[2], so[2], "thc")
 
 
+def test_search_radius_beyond_lds_halo_generic(hipctx, oracles):
+    """Same for the host-model flavour, whose global-memory path derives t0 on the spot."""
+    nx, ny, nz = 200, 120, 3
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    # a fabricated distance field: every cell within 11 cells of the coast is "in the band"
+    # (the flavour's maxdist is fixed at 180 km), so interior band cells need radii up to 12
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=9000.0, kwin=11)
+    cdist = np.where(np.abs(cdist) < 12000.0, np.sign(cdist) * np.minimum(np.abs(cdist), 179.0), cdist)
+    p = synth.pressure_3d(st, nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    hipctx.set_search_radius_hint(8)
+    try:
+        for tn in (1, 2):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        c = hipctx.last_counters()
+    finally:
+        hipctx.set_search_radius_hint(16)
+    assert orc.last_nn_max > 8 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
+    for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+        _assert_close64(a, b, nm)
+
+
 def test_no_band_and_one_class(hipctx):
     nx, ny, nz = 70, 20, 2
     dt = np.float64
