@@ -30,7 +30,7 @@ struct sb_ctx {
     int radius_hint = 16;
     int ncu = 256;              // compute units of the device
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd, coastbits;
     int tiles_n = 0, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
@@ -410,7 +410,8 @@ int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const
     HIPCHK(c, hipMemcpyAsync(c->vecs.p, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));   // hv is a local: the copy must land before it dies
     const T *dphi = (const T *)c->vecs.p, *dlam = dphi + ny;
-    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, st));
+    if ((rc = ensure(c, c->coastbits, (size_t)ny * ((nx + 63) / 64) * sizeof(uint64_t)))) return rc;
+    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, (uint64_t *)c->coastbits.p, st));
     // a distance field made here bounds the search radius of the following diag calls
     c->radius_hint = k + 1;
     return SB_OK;
@@ -505,7 +506,7 @@ int sb_destroy(sb_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd})
+    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd, &c->coastbits})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);

@@ -101,6 +101,79 @@ __global__ __launch_bounds__(256) void k_dist(const T *__restrict__ coast, const
     else cdist[o] = (mask[o] > T(0)) ? m : -m;                   // ref :179-183
 }
 
+// ------------------------------------------------------------------------------------
+// Bit-plane form of k_dist for windows of at most 63 columns (k <= 31, every BASELINE
+// grid): k_coastbits packs coast > 0 into one 64-bit word per 64-cell longitude segment
+// (a wave ballot); k_dist_bits pulls the (2k+1)-column window of each source row out of at
+// most four words and visits set bits only.  Nine targets in ten have an empty window and
+// cost a few hundred instructions instead of (2k+1)^2 byte probes.  Same arithmetic per
+// coast hit as k_dist, same early/late bookkeeping, same results.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_coastbits(const T *__restrict__ coast, uint64_t *__restrict__ bits,
+                                                   int nx, int ny, int nw) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const bool c = x < nx && coast[(size_t)y * nx + x] > T(0);       // ref: sobel.f90:157
+    const uint64_t w = __ballot(c);
+    if ((threadIdx.x & 63) == 0 && (x >> 6) < nw) bits[(size_t)y * nw + (x >> 6)] = w;
+}
+
+// bits p .. p+l-1 (l <= 63, p+l <= nx) of a row of the plane
+__device__ __forceinline__ uint64_t row_bits(const uint64_t *__restrict__ rw, int p, int l) {
+    const int w = p >> 6, o = p & 63;
+    uint64_t v = rw[w] >> o;
+    if (o + l > 64) v |= rw[w + 1] << (64 - o);
+    return v & ((1ull << l) - 1ull);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dist_bits(const uint64_t *__restrict__ bits, const T *__restrict__ mask,
+                                                   const T *__restrict__ phi, const T *__restrict__ lamf,
+                                                   T *__restrict__ cdist, int nx, int ny, int nw, int k,
+                                                   T maxdist) {
+    const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    if (xx >= nx) return;
+    const T R = T(6370.9989);                                   // ref: sobel.f90:115
+    const T big = T(12000.);
+    const T phit = phi[yy], lamt = lamf[xx];
+    const T cost = cos(phit);
+    const int L = 2 * k + 1;
+    int start = (xx - k) % nx;                                   // first window column, circular
+    if (start < 0) start += nx;
+    const int len1 = L < nx - start ? L : nx - start;
+    T m_early = big, m_late = big;
+    for (int ii = -k; ii <= k; ++ii) {
+        const int ys = yy + ii;
+        if (ys < 0 || ys >= ny) continue;                        // clamped rows add no new sources
+        const uint64_t *rw = bits + (size_t)ys * nw;
+        uint64_t wb = row_bits(rw, start, len1);
+        if (len1 < L) wb |= row_bits(rw, 0, L - len1) << len1;
+        if (!wb) continue;
+        const T phis = phi[ys];
+        const T dphi = phis - phit;                              // phi1(i) - phi1(yy)
+        const T sp = sin(dphi / T(2));
+        const T cosp = cos(phis);
+        while (wb) {
+            const int b = __builtin_ctzll(wb);
+            wb &= wb - 1;
+            int xs = start + b;
+            if (xs >= nx) xs -= nx;
+            const T dlam = lamf[xs] - lamt;                      // l1 - l2
+            const T sl = sin(dlam / T(2));
+            const T a = sp * sp + (cosp * (cost * (sl * sl)));   // ref: sobel.f90:176
+            const T c = (R * T(2)) * atan2(sqrt(a), sqrt(T(1) - a)) + T(0.5);   // ref :177
+            const bool early = (ys < yy) || (ys == yy && xs <= xx);
+            if (early) m_early = c < m_early ? c : m_early;
+            else m_late = c < m_late ? c : m_late;
+        }
+    }
+    if (m_early > T(2) * maxdist) m_early = big;                 // ref: sobel.f90:188 at sweep time
+    const T m = m_early < m_late ? m_early : m_late;
+    const size_t o = (size_t)yy * nx + xx;
+    if (m >= big) cdist[o] = big;
+    else cdist[o] = (mask[o] > T(0)) ? m : -m;                   // ref :179-183
+}
+
 template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st) {
     Geo g;
@@ -111,7 +184,14 @@ hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, 
 
 template <typename T>
 hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
-                          int k, T maxdist, hipStream_t st) {
+                          int k, T maxdist, uint64_t *bits, hipStream_t st) {
+    if (bits && k <= 31 && 2 * k + 1 <= nx) {
+        const int nw = (nx + 63) / 64;
+        hipLaunchKernelGGL(k_coastbits<T>, dim3((nx + 255) / 256, ny), dim3(256), 0, st, coast, bits, nx, ny, nw);
+        hipLaunchKernelGGL(k_dist_bits<T>, dim3((nx + 255) / 256, ny), dim3(256), 0, st, bits, mask, phi, lamf, cdist,
+                           nx, ny, nw, k, maxdist);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(64 + 2 * k) * (SB_DIST_TY + 2 * k);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_dist<T>, dim3((nx + 63) / 64, (ny + SB_DIST_TY - 1) / SB_DIST_TY), dim3(256), lds, st, coast, mask,
@@ -122,6 +202,6 @@ hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *
 template hipError_t sb_launch_edges<float>(const float *, const float *, float *, int, int, int, int, hipStream_t);
 template hipError_t sb_launch_edges<double>(const double *, const double *, double *, int, int, int, int, hipStream_t);
 template hipError_t sb_launch_dist<float>(const float *, const float *, const float *, const float *, float *, int,
-                                          int, int, float, hipStream_t);
+                                          int, int, float, uint64_t *, hipStream_t);
 template hipError_t sb_launch_dist<double>(const double *, const double *, const double *, const double *, double *,
-                                           int, int, int, double, hipStream_t);
+                                           int, int, int, double, uint64_t *, hipStream_t);

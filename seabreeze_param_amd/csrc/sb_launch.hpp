@@ -35,4 +35,5 @@ hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, 
 // phi: d2r*lat (ny), lamf: folded d2r*lon (nx), both device pointers
 template <typename T>
 hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
-                          int k, T maxdist, hipStream_t st);
+                          int k, T maxdist, uint64_t *bits,   // bits: ny*ceil(nx/64) words of workspace, or nullptr
+                          hipStream_t st);
