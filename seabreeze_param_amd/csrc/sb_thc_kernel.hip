@@ -99,7 +99,23 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
 
-    // ---- ordered list of active tiles; this workgroup keeps every gridDim-th entry ------
+    // ---- ordered list of active tiles ------------------------------------------------------
+    // Workgroups b and b+8 are observed to share an XCD (and its 4 MB L2); speed only, never
+    // correctness.  Each XCD therefore gets a contiguous eighth of the row-major list, dealt
+    // round-robin to its workgroups: tiles staged at the same time on one XCD are neighbours,
+    // and the halo cells they share are fetched from HBM once.
+    int total_active = 0;
+    for (int t0i = 0; t0i < ntiles; t0i += NT) {
+        const int t = t0i + tid;
+        const uint64_t bm = __ballot((t < ntiles) && (job.tile_nnmax[t] != 0));
+        if (lane == 0) s_wcnt[wv] = __popcll(bm);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) total_active += s_wcnt[w];
+        __syncthreads();
+    }
+    const bool xcd_map = (gridDim.x % 8 == 0);
+    const int per = (total_active + 7) / 8, nper = (int)gridDim.x / 8;
     int base = 0;
     for (int t0i = 0; t0i < ntiles; t0i += NT) {
         const int t = t0i + tid;
@@ -116,15 +132,29 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
         }
         if (flag) {
             const int pos = base + before + __popcll(bm & ((1ull << lane) - 1ull));
-            if (pos % (int)gridDim.x == (int)blockIdx.x) {
-                const int slot = pos / (int)gridDim.x;
-                if (slot < THC_MAXMINE) s_mine[slot] = t;
+            int owner, slot;
+            if (xcd_map) {
+                const int xq = pos / per, ii = pos - xq * per;
+                owner = xq + 8 * (ii % nper);
+                slot = ii / nper;
+            } else {
+                owner = pos % (int)gridDim.x;
+                slot = pos / (int)gridDim.x;
             }
+            if (owner == (int)blockIdx.x && slot < THC_MAXMINE) s_mine[slot] = t;
         }
         base += total;
         __syncthreads();
     }
-    int nmine = base > (int)blockIdx.x ? (base - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    int nmine;
+    if (xcd_map) {
+        const int xq = (int)blockIdx.x % 8, local = (int)blockIdx.x / 8;
+        int cnt = total_active - xq * per;
+        cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
+        nmine = cnt > local ? (cnt - 1 - local) / nper + 1 : 0;
+    } else {
+        nmine = base > (int)blockIdx.x ? (base - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    }
     if (nmine > THC_MAXMINE) nmine = THC_MAXMINE;    // the launcher sizes the grid so this never binds
     for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
@@ -156,88 +186,90 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
         // sea_breeze_diag.f90:167) left by k_gz in the same workspace for the tiles that need it
         int X, Y;
         sb_map_cell(g, x0, y0, X, Y);
-        const size_t i00 = (size_t)Y * g.nxh + X;
+        const unsigned unxh = (unsigned)g.nxh;
+        const unsigned i00 = (unsigned)Y * unxh + (unsigned)X;
         T c_th = T(0), c_gz = T(0), c_t0 = T(0);
         if constexpr (FLY) { c_th = job.theta[i00]; c_gz = job.t0[i00]; }
         else c_t0 = job.t0[i00];
-        double c0 = 0.0;
-        unsigned mine = 0;
-        // rows are staged RB at a time: all their loads are issued before any result is used
-        constexpr int RB = RPW;
+        // array column of each of my NCH chunks (-1: no such cell): the longitude map is the
+        // same for every row this thread stages, so it is evaluated once per tile
+        int xcol[NCH];
 #pragma unroll
-        for (int rb = 0; rb < RPW; rb += RB) {
-            T dv[RB * NCH], zv[FLY ? RB * NCH : 1];
-            uint64_t lw[RB * NCH];
-            int xc[RB * NCH];
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * SB_WAVE + lane;
+            const int xs = x0 - H + c;
+            bool ok = c < W;
+            int Xc = 0;
+            if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
+            else if (fastx) {
+                if (g.bnd == BND_WRAPPER) {
+                    int m = xs + 1;
+                    m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
+                    Xc = (m < 1 ? 1 : m) - 1;
+                } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
+            } else {
+                int Yd;
+                sb_map_cell(g, xs, y0, Xc, Yd);
+            }
+            xcol[ch] = ok ? Xc : -1;
+        }
+        // every global load of the tile is issued before any result is used
+        T dv[RPW * NCH], zv[FLY ? RPW * NCH : 1];
+        uint64_t lw[RPW * NCH];
+        unsigned rowmask = 0;
 #pragma unroll
-            for (int rj = 0; rj < RB; ++rj) {
-                const int ri = rb + rj;
-                const int r = wv + ri * NWV;
-                const int ys = y0 - H + r;
-                int Yr;
-                bool rowok = ri < RPW && r < HT;
-                if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = rowok && (Yr >= 0 && Yr < g.nyh); }
-                else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+        for (int ri = 0; ri < RPW; ++ri) {
+            const int r = wv + ri * NWV;
+            const int ys = y0 - H + r;
+            int Yr;
+            bool rowok = r < HT;
+            if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = rowok && (Yr >= 0 && Yr < g.nyh); }
+            else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+            rowmask |= (rowok ? 1u : 0u) << ri;
+            const unsigned rowbase = (unsigned)Yr * unxh, wordbase = (unsigned)Yr * (unsigned)g.nw;
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int c = ch * SB_WAVE + lane;
-                    const int xs = x0 - H + c;
-                    bool ok = rowok && c < W;
-                    int Xc = 0;
-                    if (fastx) {
-                        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
-                        else if (g.bnd == BND_WRAPPER) {
-                            int m = xs + 1;
-                            m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
-                            Xc = (m < 1 ? 1 : m) - 1;
-                        } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
-                    } else {
-                        int Yd;
-                        ok = ok && sb_map_cell(g, xs, ys, Xc, Yd);
-                    }
-                    const int k = rj * NCH + ch;
-                    xc[k] = ok ? Xc : -1;
-                    dv[k] = T(0);
-                    lw[k] = 0;
-                    if constexpr (FLY) zv[k] = T(0);
-                    if (ok) {
-                        const size_t ii = (size_t)Yr * g.nxh + Xc;
-                        if constexpr (FLY) { dv[k] = job.theta[ii]; zv[k] = job.t0[ii]; }
-                        else dv[k] = job.t0[ii];
-                        lw[k] = job.clsbits[(size_t)Yr * g.nw + (Xc >> 6)];
-                    }
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = ri * NCH + ch;
+                dv[k] = T(0);
+                lw[k] = 0;
+                if constexpr (FLY) zv[k] = T(0);
+                if (rowok && xcol[ch] >= 0) {
+                    const unsigned ii = rowbase + (unsigned)xcol[ch];
+                    if constexpr (FLY) { dv[k] = job.theta[ii]; zv[k] = job.t0[ii]; }
+                    else dv[k] = job.t0[ii];
+                    lw[k] = job.clsbits[wordbase + ((unsigned)xcol[ch] >> 6)];
                 }
             }
-            if (rb == 0) {
-                if constexpr (FLY) c_t0 = c_th - c_gz;
-                c0 = (double)c_t0;
+        }
+        if constexpr (FLY) c_t0 = c_th - c_gz;
+        const double c0 = (double)c_t0;
+        unsigned mine = 0;
 #pragma unroll
-                for (int q = 0; q < CPT; ++q) mine |= (unsigned)((bw[q] >> ((x0 + lx + g.h) & 63)) & 1ull) << q;
-            }
-            // ---- into LDS; the land-side count is prefixed along the row on the way in with a
-            // ballot + popcount, so only the two fp64 tables need a longitude scan ------------
+        for (int q = 0; q < CPT; ++q) mine |= (unsigned)((bw[q] >> ((x0 + lx + g.h) & 63)) & 1ull) << q;
+        // ---- into LDS; the land-side count is prefixed along the row on the way in with a
+        // ballot + popcount, so only the two fp64 tables need a longitude scan ----------------
 #pragma unroll
-            for (int rj = 0; rj < RB; ++rj) {
-                const int r = wv + (rb + rj) * NWV;
-                unsigned carryC = 0;
+        for (int ri = 0; ri < RPW; ++ri) {
+            const int r = wv + ri * NWV;
+            const bool rowok = (rowmask >> ri) & 1u;
+            unsigned carryC = 0;
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int k = rj * NCH + ch;
-                    const int c = ch * SB_WAVE + lane;
-                    const bool ok = xc[k] >= 0;
-                    const int land = ok ? (int)((lw[k] >> (xc[k] & 63)) & 1ull) : 0;
-                    T t0v = dv[k];
-                    if constexpr (FLY) t0v = dv[k] - zv[k];
-                    const double d = ok ? (double)t0v - c0 : 0.0;
-                    const uint64_t lm = __ballot(land);
-                    const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
-                    carryC += (unsigned)__popcll(lm);
-                    if (rb + rj < RPW && r < HT && c < W) {
-                        const int o = (r + 1) * P + c + 1;
-                        sA[o] = d;
-                        sL[o] = land ? d : 0.0;
-                        sC[o] = (unsigned short)cn;
-                    }
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = ri * NCH + ch;
+                const int c = ch * SB_WAVE + lane;
+                const bool ok = rowok && xcol[ch] >= 0;
+                const int land = ok ? (int)((lw[k] >> (xcol[ch] & 63)) & 1ull) : 0;
+                T t0v = dv[k];
+                if constexpr (FLY) t0v = dv[k] - zv[k];
+                const double d = ok ? (double)t0v - c0 : 0.0;
+                const uint64_t lm = __ballot(land);
+                const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
+                carryC += (unsigned)__popcll(lm);
+                if (r < HT && c < W) {
+                    const int o = (r + 1) * P + c + 1;
+                    sA[o] = d;
+                    sL[o] = land ? d : 0.0;
+                    sC[o] = (unsigned short)cn;
                 }
             }
         }
@@ -393,7 +425,7 @@ hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st) 
     // one workgroup per CU; more only if a workgroup could own more tiles than its list holds
     const int ntiles = job.thc_ntx * job.thc_nty;
     int nblocks = ncu;
-    while ((ntiles + nblocks - 1) / nblocks > THC_MAXMINE) nblocks *= 2;
+    while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
     if (H <= 8) launch_thc<T, 32, 8>(job, nblocks, st);
     else if (H <= 16) launch_thc<T, 32, 16>(job, nblocks, st);
     else launch_thc<T, 16, 24>(job, nblocks, st);
