@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--nz", type=int, default=56)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline per variant")
+    ap.add_argument("--comm", choices=("native", "torch", "gloo"), default="native",
+                    help="N>1: ghost rows + moments over the library's own RCCL communicator (native; the "
+                         "control plane is gloo), over torch.distributed's nccl backend (torch), or over gloo "
+                         "(rehearsal of the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     args = ap.parse_args()
@@ -127,10 +131,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.comm == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
+    comm = args.comm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if comm in ("native", "gloo"):
+            dist.init_process_group("gloo")
+            if comm == "gloo":
+                comm = "torch"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     nx, ny, nz = args.nx, args.ny, args.nz
     dt = np.float64
@@ -140,6 +152,19 @@ def main():
     t_gen = time.perf_counter()
     st = synth.static_fields(nx, ny, dt)
     ctx = hip.Context(local_rank)
+    if world > 1 and comm == "native":
+        # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
+        uid = [hip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ok = torch.ones(1, dtype=torch.int32)
+        try:
+            ctx.comm_init(uid[0], rank, world)
+        except hip.SeabreezeHipError as e:
+            print(f"[bench rank {rank}] native RCCL init failed: {e}", file=sys.stderr, flush=True)
+            ok[0] = 0
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            comm = "torch"          # exchange through torch.distributed (gloo) instead: slow, still correct
     coast = ctx.get_edges(st.landfrac, st.icefrac)                    # HIP (product) setup chain
     cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     kwin = hip.dist_window(st.lon, st.lat)
@@ -153,7 +178,8 @@ def main():
     u_full, v_full = synth.wind_step(st, nz, 1, dt, rows=rows)
     gen_s = time.perf_counter() - t_gen
 
-    runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1)
+    runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1,
+                        comm=comm if world > 1 else "torch")
     runner.upload_static(st.z, st.sigma, cdist)
     # two input sets at different addresses: B swaps u and v (distinct synthetic winds) and
     # uses the next step's theta, so no step re-reads the lines the previous one fetched
@@ -181,7 +207,8 @@ def main():
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -224,6 +251,7 @@ def main():
             "band_fraction": n_band_total / (nx * ny),
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
+            "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
             "input_gen_s": round(gen_s, 1),
         },
         "roofline": {
@@ -256,6 +284,8 @@ def main():
         }
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -240,6 +240,30 @@ int sb_dist_window_f64(int nlons, int nlats, const double *lon, const double *la
 int sb_dist_window_f32(int nlons, int nlats, const float *lon, const float *lat, float maxdist, int *k);
 
 /* -------------------------------------------------------------------------------- */
+/* swap_bounds -- ghost-cell fill of one latitude band of a multi-GPU run            */
+/* replaces: subroutine swap_bounds(field, halo_size)                                */
+/*           ref: generic/halo_exchange_mod.f90:12-17 (an empty stub; the UM copy    */
+/*           calls a real one, ref: UM/vn10.7/sea_breeze_diag.F90:408-410)            */
+/* One process per GPU owns `ny` rows x full longitude circles inside a frame of     */
+/* `halo` ghost cells: field is (nx+2*halo, ny+2*halo) in DEVICE memory.  North and   */
+/* south ghost rows are exchanged with the band neighbours (ranks rank-1 / rank+1)    */
+/* by ncclSend/ncclRecv in one group over RCCL (xGMI); bands at rank 0 / nranks-1     */
+/* replicate their pole-side edge row; E-W ghost columns are the periodic wrap.       */
+/* Without sb_comm_init the context is a single band owning the globe (local fill).  */
+/* librccl.so is opened on demand by sb_comm_get_unique_id / sb_comm_init.           */
+/*   rank 0:    sb_comm_get_unique_id(id);  -- hand the 128 bytes to every rank       */
+/*   every rank: sb_comm_init(ctx, id, rank, nranks);                                 */
+/* sb_allgather_moments_dev: the 5-double sigma moments of every band, in rank order, */
+/* for sb_use_gathered_moments (ncclAllGather).                                       */
+/* -------------------------------------------------------------------------------- */
+int sb_comm_get_unique_id(unsigned char id[128]);
+int sb_comm_init(sb_ctx *ctx, const unsigned char id[128], int rank, int nranks);
+int sb_comm_finalize(sb_ctx *ctx);
+int sb_swap_bounds_f64_dev(sb_ctx *ctx, double *field, int nx, int ny, int halo, void *stream);
+int sb_swap_bounds_f32_dev(sb_ctx *ctx, float *field, int nx, int ny, int halo, void *stream);
+int sb_allgather_moments_dev(sb_ctx *ctx, const double *mine5, double *gathered, void *stream);
+
+/* -------------------------------------------------------------------------------- */
 /* get_threads  ref: sobel.f90:195-206 (OpenMP thread count there; here the number   */
 /* of visible HIP devices -- the unit of parallelism a caller can spread bands over) */
 /* -------------------------------------------------------------------------------- */

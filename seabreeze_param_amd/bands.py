@@ -66,7 +66,12 @@ class BandRunner:
     """Owns one rank's device-resident fields and runs seabreeze_diag steps on them."""
 
     def __init__(self, ctx: _hip.Context, torch, dist, rank: int, world: int, nx: int, ny: int, nz: int,
-                 halo: int, dtype=np.float64):
+                 halo: int, dtype=np.float64, comm: str = "torch"):
+        """comm="torch": ghost rows and moments travel through torch.distributed (`dist`, any backend);
+        comm="native": through the library's own RCCL communicator (ctx.comm_init must have run):
+        ncclSend/ncclRecv + ncclAllGather enqueued on the compute stream by two C-ABI calls."""
+        assert comm in ("torch", "native")
+        self.comm = comm
         self.ctx, self.torch, self.dist = ctx, torch, dist
         self.rank, self.world = rank, world
         self.nx, self.ny, self.nz = nx, ny, nz
@@ -98,8 +103,12 @@ class BandRunner:
 
     def _fill_ghosts(self, loc):
         if self.world > 1:
-            exchange_ns(loc, self.nyl, self.h, self.rank, self.world, self.dist, self.torch)
-            fill_ew_ghosts(loc, self.nx, self.h)
+            if self.comm == "native":
+                self.ctx.swap_bounds_dev(self.dtype, loc.data_ptr(), self.nx, self.nyl, self.h,
+                                         self.torch.cuda.current_stream().cuda_stream)
+            else:
+                exchange_ns(loc, self.nyl, self.h, self.rank, self.world, self.dist, self.torch)
+                fill_ew_ghosts(loc, self.nx, self.h)
 
     def upload_static(self, z, sigma, mask):
         self.z, self.sigma, self.mask = (self._halo_field(a) for a in (z, sigma, mask))
@@ -125,7 +134,10 @@ class BandRunner:
         if self.world > 1:
             self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
                                        self.mom.data_ptr(), stream)
-            self.dist.all_gather_into_tensor(self.gath, self.mom)
+            if self.comm == "native":
+                self.ctx.allgather_moments_dev(self.mom.data_ptr(), self.gath.data_ptr(), stream)
+            else:
+                self.dist.all_gather_into_tensor(self.gath, self.mom)
             self._fill_ghosts(s["theta"])               # theta changes every step
         self.ctx.seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h, self.bnd,
                                     s["p"].data_ptr(), s["u"].data_ptr(), s["v"].data_ptr(),

@@ -6,6 +6,9 @@
 #include "../../include/seabreeze_hip.h"
 #include "sb_launch.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,6 +51,10 @@ struct sb_ctx {
     int ngathered = 0;
     std::vector<hipEvent_t> prof_ev;
     int prof_calls = 0, prof_max = 0;
+    // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
+    void *rccl_lib = nullptr;
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
 };
 
 namespace {
@@ -504,6 +511,7 @@ int sb_create(sb_ctx **out, int device) {
 int sb_destroy(sb_ctx *c) {
     if (!c) return SB_OK;
     (void)hipSetDevice(c->device);
+    if (c->comm) (void)sb_comm_finalize(c);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd, &c->coastbits})
@@ -669,3 +677,143 @@ SB_DEFINE(double, f64)
 SB_DEFINE(float, f32)
 
 }  // extern "C"
+
+// --------------------------------------------------------------------------------------
+// Latitude-band communication over RCCL (xGMI).  librccl.so is opened on demand, so the
+// library loads and every single-GPU entry point works without it.
+// --------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+    void *lib = nullptr;
+} g_rccl;
+
+int rccl_load(sb_ctx *c) {
+    if (g_rccl.lib) return SB_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(c, SB_ERR_COMM, std::string("cannot load librccl.so: ") + dlerror());
+#define SB_RCCL_SYM(field, name)                                                        \
+    *(void **)(&g_rccl.field) = dlsym(lib, name);                                       \
+    if (!g_rccl.field) return fail(c, SB_ERR_COMM, std::string("librccl.so lacks ") + name);
+    SB_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    SB_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    SB_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    SB_RCCL_SYM(GroupStart, "ncclGroupStart")
+    SB_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    SB_RCCL_SYM(Send, "ncclSend")
+    SB_RCCL_SYM(Recv, "ncclRecv")
+    SB_RCCL_SYM(AllGather, "ncclAllGather")
+    SB_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef SB_RCCL_SYM
+    g_rccl.lib = lib;
+    return SB_OK;
+}
+
+#define NCCLCHK(c, call)                                                                              \
+    do {                                                                                              \
+        ncclResult_t r__ = (call);                                                                    \
+        if (r__ != ncclSuccess) return fail((c), SB_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r__)); \
+    } while (0)
+
+template <typename T>
+int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!field || nx < 1 || ny < 1 || halo < 0) return fail(c, SB_ERR_ARG, "bad swap_bounds arguments");
+    if (halo == 0) return SB_OK;
+    if (c->nranks > 1 && ny < halo) return fail(c, SB_ERR_ARG, "band thinner than the halo");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const size_t rowlen = (size_t)nx + 2 * halo, slab = rowlen * halo;
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    const bool south = c->rank == 0, north = c->rank == c->nranks - 1;
+    if (c->nranks > 1) {
+        // one group: my first/last `halo` interior rows out, the neighbours' into my ghost rows
+        ncclComm_t comm = (ncclComm_t)c->comm;
+        NCCLCHK(c, g_rccl.GroupStart());
+        if (!south) {
+            NCCLCHK(c, g_rccl.Send(field + slab, slab, dt, c->rank - 1, comm, st));
+            NCCLCHK(c, g_rccl.Recv(field, slab, dt, c->rank - 1, comm, st));
+        }
+        if (!north) {
+            NCCLCHK(c, g_rccl.Send(field + rowlen * ny, slab, dt, c->rank + 1, comm, st));
+            NCCLCHK(c, g_rccl.Recv(field + rowlen * (ny + halo), slab, dt, c->rank + 1, comm, st));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+    }
+    HIPCHK(c, sb_launch_fill_ghosts<T>(field, nx, ny, halo, south ? 1 : 0, north ? 1 : 0, st));
+    return SB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sb_comm_get_unique_id(unsigned char id[128]) {
+    if (!id) return fail(nullptr, SB_ERR_ARG, "null pointer");
+    int rc = rccl_load(nullptr);
+    if (rc) return rc;
+    ncclUniqueId u;
+    ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, SB_ERR_COMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+    static_assert(sizeof(u.internal) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id, u.internal, 128);
+    return SB_OK;
+}
+
+int sb_comm_init(sb_ctx *c, const unsigned char id[128], int rank, int nranks) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, SB_ERR_ARG, "bad communicator arguments");
+    if (c->comm) return fail(c, SB_ERR_ARG, "communicator already initialised");
+    int rc = rccl_load(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, 128);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, g_rccl.CommInitRank(&comm, nranks, u, rank));
+    c->comm = comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    return SB_OK;
+}
+
+int sb_comm_finalize(sb_ctx *c) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        NCCLCHK(c, g_rccl.CommDestroy((ncclComm_t)c->comm));
+    }
+    c->comm = nullptr;
+    c->rank = 0;
+    c->nranks = 1;
+    return SB_OK;
+}
+
+int sb_swap_bounds_f64_dev(sb_ctx *c, double *field, int nx, int ny, int halo, void *stream) {
+    return swap_bounds_dev<double>(c, field, nx, ny, halo, stream);
+}
+int sb_swap_bounds_f32_dev(sb_ctx *c, float *field, int nx, int ny, int halo, void *stream) {
+    return swap_bounds_dev<float>(c, field, nx, ny, halo, stream);
+}
+
+int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!mine5 || !gathered) return fail(c, SB_ERR_ARG, "null pointer");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (c->nranks == 1) {
+        HIPCHK(c, hipMemcpyAsync(gathered, mine5, 5 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return SB_OK;
+    }
+    NCCLCHK(c, g_rccl.AllGather(mine5, gathered, 5, ncclDouble, (ncclComm_t)c->comm, st));
+    return SB_OK;
+}
+
+}  // extern "C"
+

@@ -37,3 +37,7 @@ template <typename T>
 hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
                           int k, T maxdist, uint64_t *bits,   // bits: ny*ceil(nx/64) words of workspace, or nullptr
                           hipStream_t st);
+
+// local part of swap_bounds: E-W periodic ghost columns, pole-side ghost rows replicate the edge row
+template <typename T>
+hipError_t sb_launch_fill_ghosts(T *field, int nx, int ny, int h, int south, int north, hipStream_t st);

@@ -214,6 +214,37 @@ class Context:
                   "sb_use_gathered_moments")
 
 
+    # ------------------------------------------------------------------ latitude-band communication (RCCL)
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        assert len(unique_id) == 128
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._chk(self.lib.sb_comm_init(self.h, buf, C.c_int(rank), C.c_int(nranks)), "sb_comm_init")
+
+    def comm_finalize(self):
+        self._chk(self.lib.sb_comm_finalize(self.h), "sb_comm_finalize")
+
+    def swap_bounds_dev(self, dtype, field, nx, ny, halo, stream=None):
+        """Ghost-cell fill of a device field (nx+2h, ny+2h): N-S rows over RCCL, poles and E-W locally."""
+        fn = getattr(self.lib, f"sb_swap_bounds_{_SFX[np.dtype(dtype)]}_dev")
+        self._chk(fn(self.h, _p(field), C.c_int(nx), C.c_int(ny), C.c_int(halo),
+                     C.c_void_p(stream) if stream else None), "sb_swap_bounds_dev")
+
+    def allgather_moments_dev(self, mine5, gathered, stream=None):
+        self._chk(self.lib.sb_allgather_moments_dev(self.h, _p(mine5), _p(gathered),
+                                                    C.c_void_p(stream) if stream else None),
+                  "sb_allgather_moments_dev")
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (call on rank 0, broadcast to every rank, pass to Context.comm_init)."""
+    lib = load_library()
+    buf = (C.c_ubyte * 128)()
+    rc = lib.sb_comm_get_unique_id(buf)
+    if rc != 0:
+        raise SeabreezeHipError(f"sb_comm_get_unique_id failed ({rc}): {lib.sb_last_error(None).decode()}")
+    return bytes(buf)
+
+
 def dist_window(lon, lat, maxdist=180.0) -> int:
     lib = load_library()
     lon = np.ascontiguousarray(lon)
