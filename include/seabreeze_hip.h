@@ -262,6 +262,21 @@ int sb_comm_finalize(sb_ctx *ctx);
 int sb_swap_bounds_f64_dev(sb_ctx *ctx, double *field, int nx, int ny, int halo, void *stream);
 int sb_swap_bounds_f32_dev(sb_ctx *ctx, float *field, int nx, int ny, int halo, void *stream);
 int sb_allgather_moments_dev(sb_ctx *ctx, const double *mine5, double *gathered, void *stream);
+/* One seabreeze_diag step of a latitude band, device pointers, as sb_seabreeze_diag_*_dev with
+   bnd = SB_BND_HALO -- plus the band's communication: the sigma moments are reduced over all
+   bands and theta's ghost cells are filled (swap_bounds) inside the call, on the context's
+   second stream, while the kernels that need neither (k_scan, k_wind) run on `stream`.
+   mask, z, sigma must already carry their ghost cells (static: exchange them once).       */
+int sb_band_seabreeze_diag_f64_dev(sb_ctx *ctx, double timestep_s, int timestep_number, int nx, int ny, int nz,
+                                   int halo, const double *p, const double *u, const double *v, double *theta,
+                                   const double *mask, const double *z, const double *sigma, double *windspeed,
+                                   double *winddir, double *thc, double *sb_con, const sb_tunables *tun,
+                                   void *stream);
+int sb_band_seabreeze_diag_f32_dev(sb_ctx *ctx, float timestep_s, int timestep_number, int nx, int ny, int nz,
+                                   int halo, const float *p, const float *u, const float *v, float *theta,
+                                   const float *mask, const float *z, const float *sigma, float *windspeed,
+                                   float *winddir, float *thc, float *sb_con, const sb_tunables *tun,
+                                   void *stream);
 
 /* -------------------------------------------------------------------------------- */
 /* get_threads  ref: sobel.f90:195-206 (OpenMP thread count there; here the number   */

@@ -131,6 +131,14 @@ class BandRunner:
     def step(self, timestep: float, tn: int, s):
         t = self.torch
         stream = t.cuda.current_stream().cuda_stream
+        if self.world > 1 and self.comm == "native":
+            # one C-ABI call: communication on the library's second stream under k_scan/k_wind
+            self.ctx.band_seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h,
+                                             s["p"].data_ptr(), s["u"].data_ptr(), s["v"].data_ptr(),
+                                             s["theta"].data_ptr(), self.mask.data_ptr(), self.z.data_ptr(),
+                                             self.sigma.data_ptr(), self.ws.data_ptr(), self.wd.data_ptr(),
+                                             self.thc.data_ptr(), self.sb_con.data_ptr(), stream)
+            return
         if self.world > 1:
             self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
                                        self.mom.data_ptr(), stream)

@@ -52,6 +52,9 @@ struct sb_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_calls = 0, prof_max = 0;
     // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
+    hipStream_t aux_stream = nullptr;   // communication of a band step runs here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf band_mom;                    // [5 own moments | 5 x nranks gathered]
     void *rccl_lib = nullptr;
     void *comm = nullptr;
     int rank = 0, nranks = 1;
@@ -104,7 +107,7 @@ int pick_halo(const sb_ctx *c) {
 
 // Prepare workspace + job; enqueue the four kernels of one diag call.
 template <typename T>
-int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st) {
+int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const Geo &g = job.g;
     const size_t ncell = (size_t)g.nxh * g.nyh;
     const size_t nbits = (size_t)g.nyh * g.nw * sizeof(uint64_t);
@@ -154,10 +157,12 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st) {
     SbLaunchCtx lc;
     lc.stream = st;
     lc.prof = nullptr;
-    if (c->prof_calls < c->prof_max) lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
+    if (phases == 3 && c->prof_calls < c->prof_max) lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
+    lc.phases = phases;
     HIPCHK(c, sb_launch_diag<T>(job, H, lc));
+    if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
     c->last_flags = flags_now;
     c->flag_parity = 1 - c->flag_parity;
     c->last_g = g;
@@ -179,7 +184,7 @@ int check_dims(sb_ctx *c, int nx, int ny, int nz, int halo, int bnd) {
 template <typename T>
 int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, int bnd, const T *p,
                        const T *u, const T *v, const T *theta, const T *mask, const T *z, const T *sigma, T *ws,
-                       T *wd, T *thc, T *sb_con, const sb_tunables *tun, void *stream) {
+                       T *wd, T *thc, T *sb_con, const sb_tunables *tun, void *stream, int phases = 3) {
     int rc = check_dims<T>(c, nx, ny, nz, halo, bnd);
     if (rc) return rc;
     if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
@@ -201,7 +206,56 @@ int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, 
     job.p = p; job.u = u; job.v = v; job.theta = theta; job.mask = mask; job.z = z; job.sigma = sigma;
     job.ws = ws; job.wd = wd; job.thc = thc; job.sb_con = sb_con; job.out = nullptr;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    return run_diag<T>(c, job, st);
+    return run_diag<T>(c, job, st, phases);
+}
+
+template <typename T>
+int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, double *moments5, void *stream);
+template <typename T>
+int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream);
+
+// One model step of a latitude band: the communication (sigma moments all-gather, theta ghost
+// rows) runs on the context's second stream while k_scan and k_wind, which need neither, run
+// on the caller's stream; the two join before the statistics merge, k_gz and k_thc.
+template <typename T>
+int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, const T *p, const T *u,
+                  const T *v, T *theta, const T *mask, const T *z, const T *sigma, T *ws, T *wd, T *thc, T *sb_con,
+                  const sb_tunables *tun, void *stream) {
+    int rc = check_dims<T>(c, nx, ny, nz, halo, SB_BND_HALO);
+    if (rc) return rc;
+    if (halo < 1) return fail(c, SB_ERR_ARG, "a band needs ghost cells (halo >= 1)");
+    if (!sigma || !theta) return fail(c, SB_ERR_ARG, "null array pointer");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (!c->aux_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
+    double *mine = (double *)c->band_mom.p, *gath = mine + 5;
+    // fork: everything that talks to the neighbours goes to the second stream
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream))) return rc;
+    if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
+    if ((rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+    // phase 1 on the caller's stream meanwhile
+    const Moments *saved_g = c->gathered;
+    const int saved_n = c->ngathered;
+    c->gathered = (const Moments *)gath;
+    c->ngathered = c->nranks;
+    rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
+                               thc, sb_con, tun, (void *)st, 1);
+    if (!rc) {
+        hipError_t e = hipStreamWaitEvent(st, c->ev_join, 0);
+        if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
+    }
+    if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma,
+                                        ws, wd, thc, sb_con, tun, (void *)st, 2);
+    c->gathered = saved_g;
+    c->ngathered = saved_n;
+    return rc;
 }
 
 template <typename T>
@@ -512,6 +566,10 @@ int sb_destroy(sb_ctx *c) {
     if (!c) return SB_OK;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)sb_comm_finalize(c);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->band_mom.p) (void)hipFree(c->band_mom.p);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd, &c->coastbits})
@@ -794,6 +852,21 @@ int sb_comm_finalize(sb_ctx *c) {
     c->rank = 0;
     c->nranks = 1;
     return SB_OK;
+}
+
+int sb_band_seabreeze_diag_f64_dev(sb_ctx *c, double dt, int tn, int nx, int ny, int nz, int halo, const double *p,
+                                   const double *u, const double *v, double *theta, const double *mask,
+                                   const double *z, const double *sigma, double *ws, double *wd, double *thc,
+                                   double *sb_con, const sb_tunables *tun, void *stream) {
+    return band_diag_dev<double>(c, dt, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con, tun,
+                                 stream);
+}
+int sb_band_seabreeze_diag_f32_dev(sb_ctx *c, float dt, int tn, int nx, int ny, int nz, int halo, const float *p,
+                                   const float *u, const float *v, float *theta, const float *mask, const float *z,
+                                   const float *sigma, float *ws, float *wd, float *thc, float *sb_con,
+                                   const sb_tunables *tun, void *stream) {
+    return band_diag_dev<float>(c, dt, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con, tun,
+                                stream);
 }
 
 int sb_swap_bounds_f64_dev(sb_ctx *c, double *field, int nx, int ny, int halo, void *stream) {

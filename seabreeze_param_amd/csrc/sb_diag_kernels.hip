@@ -471,10 +471,12 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     hipStream_t st = lc.stream;
     hipEvent_t *ev = lc.prof;
     static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 7;   // tuning knob (diagnostic)
-    // ---- k_scan (+ merge of the statistics) ---------------------------------------------
-    if (ev) (void)hipEventRecord(ev[0], st);
-    {
-        const bool gathered = lc.gathered != nullptr;
+    const bool gathered = lc.gathered != nullptr;
+    const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
+    // ---- phase 1: needs neither theta's ghost cells nor the statistics -----------------------
+    if (ph1) {
+        // k_scan (+ merge of the statistics when they are this domain's own)
+        if (ev) (void)hipEventRecord(ev[0], st);
         const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
         int nblk = (int)((nseg + 79) / 80);                      // 16 waves x 5 segments per trip
         if (nblk < 1) nblk = 1;
@@ -483,37 +485,38 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (spt <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
         else if (spt <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
         else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
-        if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
-                                         (T *)lc.stats);
-        else hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk,
-                                (T *)lc.stats, (Moments *)nullptr);
-    }
-    if (ev) (void)hipEventRecord(ev[1], st);
-    // ---- k_wind --------------------------------------------------------------------------
-    {
+        if (!gathered) hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk,
+                                          (T *)lc.stats, (Moments *)nullptr);
+        if (ev) (void)hipEventRecord(ev[1], st);
+        // k_wind
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
         static const bool plain = getenv("SB_WIND_PLAIN") != nullptr;   // tuning knob (diagnostic)
         if (plain) hipLaunchKernelGGL((k_wind<T, 7, false>), wg, wb, 0, st, job);
         else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
         else if (un <= 7) hipLaunchKernelGGL((k_wind<T, 7, true>), wg, wb, 0, st, job);
         else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
+        if (ev) (void)hipEventRecord(ev[2], st);
     }
-    if (ev) (void)hipEventRecord(ev[2], st);
-    // ---- k_t0 (f2py flavour: t0 everywhere) / k_gz (host-model flavour: gz near the band) ------
-    if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-    else {
-        const int TY = job.thc_ty;
-        // tiles to look at around a tile: the halo H in tile units; one more column at the
-        // longitude seam when the last tile column is narrower than a tile
-        const int dyt = (H + TY - 1) / TY, dxt = 1 + ((g.nx & 63) ? 1 : 0);
-        const dim3 gg = g.h > 0 ? dim3((g.nxh + 63) / 64, (g.nyh + TY - 1) / TY) : dim3(job.thc_ntx, (g.ny + TY - 1) / TY);
-        hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
+    // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
+    if (ph2) {
+        if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
+                                         (T *)lc.stats);
+        // k_t0 (f2py flavour: t0 everywhere) / k_gz (host-model flavour: gz near the band)
+        if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+        else {
+            const int TY = job.thc_ty;
+            // tiles to look at around a tile: the halo H in tile units; one more column at the
+            // longitude seam when the last tile column is narrower than a tile
+            const int dyt = (H + TY - 1) / TY, dxt = 1 + ((g.nx & 63) ? 1 : 0);
+            const dim3 gg = g.h > 0 ? dim3((g.nxh + 63) / 64, (g.nyh + TY - 1) / TY) : dim3(job.thc_ntx, (g.ny + TY - 1) / TY);
+            hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
+        }
+        if (ev) (void)hipEventRecord(ev[3], st);
+        // k_thc: contrast + thresholds + state update
+        hipError_t e = sb_launch_thc<T>(job, H, lc.ncu, st);
+        if (e != hipSuccess) return e;
+        if (ev) (void)hipEventRecord(ev[4], st);
     }
-    if (ev) (void)hipEventRecord(ev[3], st);
-    // ---- k_thc: contrast + thresholds + state update ---------------------------------------
-    hipError_t e = sb_launch_thc<T>(job, H, lc.ncu, st);
-    if (e != hipSuccess) return e;
-    if (ev) (void)hipEventRecord(ev[4], st);
     return hipGetLastError();
 }
 

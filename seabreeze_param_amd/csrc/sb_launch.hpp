@@ -17,6 +17,8 @@ struct SbLaunchCtx {
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
     int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
+    int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
+                                    // bit 1: statistics merge, k_t0/k_gz, k_thc.  3 = the whole call
 };
 
 template <typename T>

@@ -229,6 +229,16 @@ class Context:
         self._chk(fn(self.h, _p(field), C.c_int(nx), C.c_int(ny), C.c_int(halo),
                      C.c_void_p(stream) if stream else None), "sb_swap_bounds_dev")
 
+    def band_seabreeze_diag_dev(self, dtype, timestep, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma,
+                                ws, wd, thc, sb_con, stream=None, tunables: Tunables | None = None):
+        """One step of a latitude band incl. its communication (moments all-gather, theta ghost rows)."""
+        dt = np.dtype(dtype)
+        fn = getattr(self.lib, f"sb_band_seabreeze_diag_{_SFX[dt]}_dev")
+        rc = fn(self.h, _CT[dt](timestep), C.c_int(tn), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo),
+                _p(p), _p(u), _p(v), _p(theta), _p(mask), _p(z), _p(sigma), _p(ws), _p(wd), _p(thc), _p(sb_con),
+                C.byref(tunables) if tunables is not None else None, C.c_void_p(stream) if stream else None)
+        self._chk(rc, "sb_band_seabreeze_diag_dev")
+
     def allgather_moments_dev(self, mine5, gathered, stream=None):
         self._chk(self.lib.sb_allgather_moments_dev(self.h, _p(mine5), _p(gathered),
                                                     C.c_void_p(stream) if stream else None),
