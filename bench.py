@@ -40,7 +40,8 @@ def algorithmic_bytes(n, n_band, nz, s=8):
     return {
         "k_scan": s * (3 * n - n_band),                    # read sigma, mask; write sb_con outside the band
         "k_wind": s * (nz + 2) * n_band,                   # p column, u, v at band cells
-        "k_t0": 0,                                         # f2py flavour only
+        "k_gz": 0,                                         # workspace only
+        "k_final": 0,                                      # its bytes are counted under k_thc
         "k_thc": s * (2 * n + 6 * n_band),                 # theta, z in; thc out; ws, wd in; sb_con, ws, wd out
         "total": s * (5 * n + (nz + 7) * n_band),
     }

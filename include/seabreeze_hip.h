@@ -89,13 +89,13 @@ int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
    Synchronises the context's stream.                                                */
 int  sb_last_counters(sb_ctx *ctx, long long counters[4]);
 int  sb_synchronize(sb_ctx *ctx);
-/* Per-kernel timing with HIP events on the stream the kernels run on.  Between
-   sb_profile_begin and sb_profile_end the first `max_calls` diag calls record five events
-   around their launches; sb_profile_end synchronises and returns the average duration in
-   ms of [0] k_scan (+ the moments merge) [1] k_wind [2] k_t0 (f2py flavour only)
-   [3] k_thc.                                                                          */
+/* Per-kernel timing with HIP events on the stream(s) the kernels run on.  Between
+   sb_profile_begin and sb_profile_end the first `max_calls` diag calls record events around
+   their launches; sb_profile_end synchronises and returns the average duration in ms of
+   [0] k_scan (+ the moments merge) [1] k_wind [2] k_gz (k_t0 for the f2py flavour) [3] k_thc
+   [4] the join with k_wind + k_final_tiles (only when k_wind runs beside k_thc).         */
 int  sb_profile_begin(sb_ctx *ctx, int max_calls);
-int  sb_profile_end(sb_ctx *ctx, double avg_ms[4], int *ncalls);
+int  sb_profile_end(sb_ctx *ctx, double avg_ms[5], int *ncalls);
 
 /* -------------------------------------------------------------------------------- */
 /* seabreeze_diag -- host-model flavour                                              */

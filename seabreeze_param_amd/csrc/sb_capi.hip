@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,6 +59,8 @@ struct sb_ctx {
     void *rccl_lib = nullptr;
     void *comm = nullptr;
     int rank = 0, nranks = 1;
+    // run k_wind on the second stream beside k_gz/k_thc (single-domain host-model flavour)
+    bool overlap = getenv("SB_OVERLAP") ? atoi(getenv("SB_OVERLAP")) != 0 : false;
 };
 
 namespace {
@@ -161,6 +164,15 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
     lc.phases = phases;
+    lc.aux_stream = nullptr; lc.fork = nullptr; lc.join = nullptr;
+    if (c->overlap && phases == 3 && job.t0_fly) {
+        if (!c->aux_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        lc.aux_stream = c->aux_stream; lc.fork = c->ev_fork; lc.join = c->ev_join;
+    }
     HIPCHK(c, sb_launch_diag<T>(job, H, lc));
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
     c->last_flags = flags_now;
@@ -633,9 +645,9 @@ int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
     HIPCHK(c, hipDeviceSynchronize());
-    // consecutive event pairs bracket k_scan (+ moments merge), k_wind, k_t0, k_thc
-    static const int first[SB_PROF_KERNELS] = {0, 1, 2, 3}, last[SB_PROF_KERNELS] = {1, 2, 3, 4};
-    double sum[SB_PROF_KERNELS] = {0, 0, 0, 0};
+    // event pairs bracket k_scan (+ moments merge), k_wind, k_t0/k_gz, k_thc, join + k_final_tiles
+    static const int first[SB_PROF_KERNELS] = {0, 2, 4, 5, 6}, last[SB_PROF_KERNELS] = {1, 3, 5, 6, 7};
+    double sum[SB_PROF_KERNELS] = {0, 0, 0, 0, 0};
     for (int i = 0; i < c->prof_calls; ++i)
         for (int k = 0; k < SB_PROF_KERNELS; ++k) {
             float ms = 0.f;

@@ -473,6 +473,10 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 7;   // tuning knob (diagnostic)
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
+    // k_wind (HBM gather, SIMDs half idle) next to k_gz/k_thc (issue-bound, little HBM traffic):
+    // with a second stream the two run side by side and a small kernel joins them
+    const bool overlap = lc.aux_stream != nullptr && lc.phases == 3 && job.t0_fly;
+    hipError_t e = hipSuccess;
     // ---- phase 1: needs neither theta's ghost cells nor the statistics -----------------------
     if (ph1) {
         // k_scan (+ merge of the statistics when they are this domain's own)
@@ -489,18 +493,27 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
                                           (T *)lc.stats, (Moments *)nullptr);
         if (ev) (void)hipEventRecord(ev[1], st);
         // k_wind
+        hipStream_t sw = st;
+        if (overlap) {
+            sw = lc.aux_stream;
+            if ((e = hipEventRecord(lc.fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(sw, lc.fork, 0)) != hipSuccess) return e;
+        }
+        if (ev) (void)hipEventRecord(ev[2], sw);
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
         static const bool plain = getenv("SB_WIND_PLAIN") != nullptr;   // tuning knob (diagnostic)
-        if (plain) hipLaunchKernelGGL((k_wind<T, 7, false>), wg, wb, 0, st, job);
-        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
-        else if (un <= 7) hipLaunchKernelGGL((k_wind<T, 7, true>), wg, wb, 0, st, job);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
-        if (ev) (void)hipEventRecord(ev[2], st);
+        if (plain) hipLaunchKernelGGL((k_wind<T, 7, false>), wg, wb, 0, sw, job);
+        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, sw, job);
+        else if (un <= 7) hipLaunchKernelGGL((k_wind<T, 7, true>), wg, wb, 0, sw, job);
+        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, sw, job);
+        if (ev) (void)hipEventRecord(ev[3], sw);
+        if (overlap && (e = hipEventRecord(lc.join, sw)) != hipSuccess) return e;
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
         if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
                                          (T *)lc.stats);
+        if (ev) (void)hipEventRecord(ev[4], st);
         // k_t0 (f2py flavour: t0 everywhere) / k_gz (host-model flavour: gz near the band)
         if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
         else {
@@ -511,11 +524,15 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             const dim3 gg = g.h > 0 ? dim3((g.nxh + 63) / 64, (g.nyh + TY - 1) / TY) : dim3(job.thc_ntx, (g.ny + TY - 1) / TY);
             hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
         }
-        if (ev) (void)hipEventRecord(ev[3], st);
-        // k_thc: contrast + thresholds + state update
-        hipError_t e = sb_launch_thc<T>(job, H, lc.ncu, st);
-        if (e != hipSuccess) return e;
-        if (ev) (void)hipEventRecord(ev[4], st);
+        if (ev) (void)hipEventRecord(ev[5], st);
+        // k_thc: contrast (+ thresholds + state update unless k_wind is still running beside it)
+        if ((e = sb_launch_thc<T>(job, H, lc.ncu, !overlap, st)) != hipSuccess) return e;
+        if (ev) (void)hipEventRecord(ev[6], st);
+        if (overlap) {
+            if ((e = hipStreamWaitEvent(st, lc.join, 0)) != hipSuccess) return e;
+            if ((e = sb_launch_final_tiles<T>(job, lc.ncu, st)) != hipSuccess) return e;
+        }
+        if (ev) (void)hipEventRecord(ev[7], st);
     }
     return hipGetLastError();
 }

@@ -5,8 +5,8 @@
 #define SB_STATS_MAX_BLOCKS 2048
 #define SB_MAX_LDS_HALO 24          // largest LDS halo k_thc is instantiated for
 #define SB_DIST_TY 4                 // rows per k_dist tile
-#define SB_PROF_EVENTS 5            // events one profiled diag call records
-#define SB_PROF_KERNELS 4           // k_scan, k_wind, k_t0, k_thc
+#define SB_PROF_EVENTS 8            // events one profiled diag call records
+#define SB_PROF_KERNELS 5           // k_scan, k_wind, k_t0/k_gz, k_thc, k_final_tiles
 
 // Everything of the context a diag launch needs besides the job itself.
 struct SbLaunchCtx {
@@ -17,6 +17,8 @@ struct SbLaunchCtx {
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
     int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
+    hipStream_t aux_stream;         // non-null: run k_wind there, side by side with k_gz/k_thc (fork/join)
+    hipEvent_t fork, join;
     int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics merge, k_t0/k_gz, k_thc.  3 = the whole call
 };
@@ -30,7 +32,9 @@ template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
 int sb_thc_tile_rows(int H);                                         // k_thc tiles are 64 x this many cells
 template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st);
+hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse_final, hipStream_t st);
+template <typename T>
+hipError_t sb_launch_final_tiles(const DiagJob<T> &job, int ncu, hipStream_t st);
 
 template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st);

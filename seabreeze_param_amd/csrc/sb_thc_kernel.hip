@@ -77,37 +77,21 @@ __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &
     return (T)(sl / nl - ss / ns);               // 0/0 -> NaN when a class is missing
 }
 
-template <typename T, int TY, int H, bool FLY>
-__global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
-    constexpr int TX = 64, NT = THC_NT;
-    constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
-    constexpr int CPT = TX * TY / NT;            // cells per thread in the search phase
-    constexpr int NWV = NT / SB_WAVE;
-    constexpr int RPW = (HT + NWV - 1) / NWV;    // LDS rows staged per wave
-    constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;   // 64-column chunks per LDS row
-    static_assert((TX * TY) % NT == 0 && CPT >= 1, "tile/thread shape");
-    static_assert((size_t)W * HT < 65536, "u16 count table");
-    static_assert(HT % 16 == 0 && W % 16 == 0, "the scans run in batches of 16");
-    __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
-    __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
-    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
-    __shared__ int s_mine[THC_MAXMINE];
-    __shared__ int s_wcnt[NWV];
-    __shared__ int s_nn;
-
-    const Geo g = job.g;
+// ------------------------------------------------------------------------------------
+// The ordered list of active tiles, as every persistent 1024-thread workgroup builds it
+// from the tile flags; returns how many entries this workgroup owns (s_mine[0..n)).
+// Workgroups b and b+8 are observed to share an XCD (and its 4 MB L2); speed only, never
+// correctness.  Each XCD therefore gets a contiguous eighth of the row-major list, dealt
+// round-robin to its workgroups: tiles staged at the same time on one XCD are neighbours,
+// and the halo cells they share are fetched from HBM once.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int ntiles, int *s_mine, int *s_wcnt) {
+    constexpr int NT = THC_NT, NWV = THC_NT / SB_WAVE;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
-
-    // ---- ordered list of active tiles ------------------------------------------------------
-    // Workgroups b and b+8 are observed to share an XCD (and its 4 MB L2); speed only, never
-    // correctness.  Each XCD therefore gets a contiguous eighth of the row-major list, dealt
-    // round-robin to its workgroups: tiles staged at the same time on one XCD are neighbours,
-    // and the halo cells they share are fetched from HBM once.
     int total_active = 0;
     for (int t0i = 0; t0i < ntiles; t0i += NT) {
         const int t = t0i + tid;
-        const uint64_t bm = __ballot((t < ntiles) && (job.tile_nnmax[t] != 0));
+        const uint64_t bm = __ballot((t < ntiles) && (flags[t] != 0));
         if (lane == 0) s_wcnt[wv] = __popcll(bm);
         __syncthreads();
 #pragma unroll
@@ -119,7 +103,7 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     int base = 0;
     for (int t0i = 0; t0i < ntiles; t0i += NT) {
         const int t = t0i + tid;
-        const bool flag = (t < ntiles) && (job.tile_nnmax[t] != 0);
+        const bool flag = (t < ntiles) && (flags[t] != 0);
         const uint64_t bm = __ballot(flag);
         if (lane == 0) s_wcnt[wv] = __popcll(bm);
         __syncthreads();
@@ -155,7 +139,58 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     } else {
         nmine = base > (int)blockIdx.x ? (base - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     }
-    if (nmine > THC_MAXMINE) nmine = THC_MAXMINE;    // the launcher sizes the grid so this never binds
+    return nmine > THC_MAXMINE ? THC_MAXMINE : nmine;    // the launcher sizes the grid so this never binds
+}
+
+// ------------------------------------------------------------------------------------
+// k_final_tiles: thresholds, scaling and state update (ref: generic/sea_breeze_diag.f90:
+// 235-266) for the band cells of every active tile, when k_thc ran side by side with k_wind
+// and could not apply them itself.  Same persistent tile walk as k_thc.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(THC_NT) void k_final_tiles(DiagJob<T> job) {
+    __shared__ int s_mine[THC_MAXMINE];
+    __shared__ int s_wcnt[THC_NT / SB_WAVE];
+    const Geo g = job.g;
+    const int tid = threadIdx.x, TY = job.thc_ty, ntx = job.thc_ntx;
+    const int nmine = thc_build_list(job.tile_nnmax, job.thc_ntx * job.thc_nty, s_mine, s_wcnt);
+    __syncthreads();
+    for (int mi = 0; mi < nmine; ++mi) {
+        const int tile = s_mine[mi];
+        const int x0 = (tile % ntx) * 64, y0 = (tile / ntx) * TY;
+        for (int i = tid; i < 64 * TY; i += THC_NT) {
+            const int x = x0 + (i & 63), y = y0 + (i >> 6);
+            if (x < g.nx && y < g.rows && sb_bit(job.bandbits, g.nw, x + g.h, y + g.h)) {
+                const size_t o = (size_t)y * g.nx + x;
+                sb_trigger_update<T>(job, o, job.thc[o], sb_trigger_load<T>(job, o));
+            }
+        }
+    }
+}
+
+template <typename T, int TY, int H, bool FLY, bool FUSE>
+__global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
+    constexpr int TX = 64, NT = THC_NT;
+    constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
+    constexpr int CPT = TX * TY / NT;            // cells per thread in the search phase
+    constexpr int NWV = NT / SB_WAVE;
+    constexpr int RPW = (HT + NWV - 1) / NWV;    // LDS rows staged per wave
+    constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;   // 64-column chunks per LDS row
+    static_assert((TX * TY) % NT == 0 && CPT >= 1, "tile/thread shape");
+    static_assert((size_t)W * HT < 65536, "u16 count table");
+    static_assert(HT % 16 == 0 && W % 16 == 0, "the scans run in batches of 16");
+    __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
+    __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
+    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
+    __shared__ int s_mine[THC_MAXMINE];
+    __shared__ int s_wcnt[NWV];
+    __shared__ int s_nn;
+
+    const Geo g = job.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
+
+    int nmine = thc_build_list(job.tile_nnmax, ntiles, s_mine, s_wcnt);
     for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
     const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
             cst[q] = SbCellState<T>{T(0), T(0), T(0), T(0)};
-            if ((mine >> q) & 1u)
+            if (FUSE && ((mine >> q) & 1u))
                 cst[q] = sb_trigger_load<T>(job, (size_t)(y0 + ly0 + q * (NT / TX)) * g.nx + (x0 + lx));
         }
         // ---- prefix along latitude: one task per (table, column), batches of 16 rows ------
@@ -400,7 +435,8 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
             }
             nnmax = max(nnmax, nn);
             const T mul = ((cw[q] >> ((x + g.h) & 63)) & 1ull) ? T(1) : T(-1);        // ref :182-186
-            sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);  // ref :216, :235-266
+            if constexpr (FUSE) sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);  // ref :216, :235-266
+            else job.thc[(size_t)y * g.nx + x] = mul * contrast;       // k_final_tiles applies :235-266
         }
         // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters)
 #pragma unroll
@@ -413,24 +449,36 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
 }
 
 template <typename T, int TY, int H>
-static void launch_thc(const DiagJob<T> &job, int nblocks, hipStream_t st) {
-    if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
-    else hipLaunchKernelGGL((k_thc<T, TY, H, false>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_t st) {
+    if (job.t0_fly && fuse) hipLaunchKernelGGL((k_thc<T, TY, H, true, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true, false>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+    else hipLaunchKernelGGL((k_thc<T, TY, H, false, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
 }
 
 int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }
 
 template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st) {
+hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse, hipStream_t st) {
     // one workgroup per CU; more only if a workgroup could own more tiles than its list holds
     const int ntiles = job.thc_ntx * job.thc_nty;
     int nblocks = ncu;
     while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
-    if (H <= 8) launch_thc<T, 32, 8>(job, nblocks, st);
-    else if (H <= 16) launch_thc<T, 32, 16>(job, nblocks, st);
-    else launch_thc<T, 16, 24>(job, nblocks, st);
+    if (H <= 8) launch_thc<T, 32, 8>(job, nblocks, fuse, st);
+    else if (H <= 16) launch_thc<T, 32, 16>(job, nblocks, fuse, st);
+    else launch_thc<T, 16, 24>(job, nblocks, fuse, st);
     return hipGetLastError();
 }
 
-template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, hipStream_t);
-template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, hipStream_t);
+template <typename T>
+hipError_t sb_launch_final_tiles(const DiagJob<T> &job, int ncu, hipStream_t st) {
+    const int ntiles = job.thc_ntx * job.thc_nty;
+    int nblocks = ncu;
+    while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
+    hipLaunchKernelGGL(k_final_tiles<T>, dim3(nblocks), dim3(THC_NT), 0, st, job);
+    return hipGetLastError();
+}
+template hipError_t sb_launch_final_tiles<float>(const DiagJob<float> &, int, hipStream_t);
+template hipError_t sb_launch_final_tiles<double>(const DiagJob<double> &, int, hipStream_t);
+
+template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, bool, hipStream_t);
+template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, bool, hipStream_t);

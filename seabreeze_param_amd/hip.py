@@ -105,13 +105,13 @@ class Context:
         self._chk(self.lib.sb_profile_begin(self.h, C.c_int(max_calls)), "sb_profile_begin")
 
     def profile_end(self):
-        """-> ({'k_scan': ms, 'k_wind': ms, 'k_t0': ms, 'k_thc': ms}, ncalls): HIP-event averages of the
-        launches of one diag call, in launch order (k_scan includes the small moments merge; k_t0 is
-        empty for the host-model flavour)."""
-        ms = (C.c_double * 4)()
+        """-> ({'k_scan', 'k_wind', 'k_gz', 'k_thc', 'k_final'} -> ms, ncalls): HIP-event averages of the
+        launches of one diag call (k_scan includes the small moments merge; k_gz is k_t0 for the f2py
+        flavour; k_final is the join with k_wind + k_final_tiles, present only in overlap mode)."""
+        ms = (C.c_double * 5)()
         n = C.c_int(0)
         self._chk(self.lib.sb_profile_end(self.h, ms, C.byref(n)), "sb_profile_end")
-        return dict(k_scan=ms[0], k_wind=ms[1], k_t0=ms[2], k_thc=ms[3]), n.value
+        return dict(k_scan=ms[0], k_wind=ms[1], k_gz=ms[2], k_thc=ms[3], k_final=ms[4]), n.value
 
     # ------------------------------------------------------------------ host-pointer API
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
