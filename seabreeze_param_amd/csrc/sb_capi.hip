@@ -59,8 +59,6 @@ struct sb_ctx {
     void *rccl_lib = nullptr;
     void *comm = nullptr;
     int rank = 0, nranks = 1;
-    // run k_wind on the second stream beside k_gz/k_thc (single-domain host-model flavour)
-    bool overlap = getenv("SB_OVERLAP") ? atoi(getenv("SB_OVERLAP")) != 0 : false;
 };
 
 namespace {
@@ -148,14 +146,16 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.nwd = (T *)c->nwd.p;
     // the host-model flavour derives t0 inside k_thc; the f2py flavour returns the t0 plane
     job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
+    // whole single-domain calls on the k_thc2 path: contrast first, k_wind applies the update
+    job.wind_final = (phases == 3 && !c->gathered && H <= 16 && !getenv("SB_OLD_THC")) ? 1 : 0;
     // one workspace field: t0 itself (f2py flavour) or gz = (gmma*z)*sigmoid(sigma) (host-model flavour)
     if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
     job.t0 = (T *)c->t0.p;
     job.stamps = nullptr;
 #ifdef SB_STAMPS
-    if ((rc = ensure(c, c->stamps, (size_t)tx * ty * 8 * sizeof(long long)))) return rc;
+    if ((rc = ensure(c, c->stamps, (size_t)tx * ty * SB_NSTAMP * sizeof(long long)))) return rc;
     job.stamps = (long long *)c->stamps.p;
-    HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, (size_t)tx * ty * 8 * sizeof(long long), st));
+    HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, (size_t)tx * ty * SB_NSTAMP * sizeof(long long), st));
 #endif
     SbLaunchCtx lc;
     lc.stream = st;
@@ -164,15 +164,6 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
     lc.phases = phases;
-    lc.aux_stream = nullptr; lc.fork = nullptr; lc.join = nullptr;
-    if (c->overlap && phases == 3 && job.t0_fly) {
-        if (!c->aux_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        lc.aux_stream = c->aux_stream; lc.fork = c->ev_fork; lc.join = c->ev_join;
-    }
     HIPCHK(c, sb_launch_diag<T>(job, H, lc));
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
     c->last_flags = flags_now;
@@ -608,7 +599,7 @@ int sb_debug_stamps(sb_ctx *c, long long *host, int ntiles_max, int *ntiles) {
     if (!c || !host || !ntiles || !c->have_last) return SB_ERR_ARG;
     HIPCHK(c, hipDeviceSynchronize());
     const int n = c->last_tiles < ntiles_max ? c->last_tiles : ntiles_max;
-    HIPCHK(c, hipMemcpy(host, c->stamps.p, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host, c->stamps.p, (size_t)n * SB_NSTAMP * sizeof(long long), hipMemcpyDeviceToHost));
     *ntiles = n;
     return SB_OK;
 }

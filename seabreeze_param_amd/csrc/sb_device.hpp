@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #define SB_WAVE 64
+#define SB_NSTAMP 32                 // diagnostic build: clock stamps per thc tile
 
 enum { SB_FLAVOUR_GENERIC = 0, SB_FLAVOUR_WRAPPER = 1 };
 enum { BND_WRAPPER = 0, BND_GLOBAL = 1, BND_HALO = 2 };
@@ -39,6 +40,52 @@ __host__ __device__ inline Moments moments_merge(const Moments &a, const Moments
     r.mx = a.mx > b.mx ? a.mx : b.mx;
     return r;
 }
+
+#ifdef __HIPCC__
+#define SB_STATS_NT 1024             // threads of every workgroup that merges moments
+
+__device__ __forceinline__ Moments wave_merge(Moments m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Moments o;
+        o.n = __shfl_down(m.n, off);
+        o.mean = __shfl_down(m.mean, off);
+        o.m2 = __shfl_down(m.m2, off);
+        o.mn = __shfl_down(m.mn, off);
+        o.mx = __shfl_down(m.mx, off);
+        m = moments_merge(m, o);
+    }
+    return m;
+}
+
+// merge across the waves of a 1024-thread workgroup; the result is valid in thread 0
+__device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
+    m = wave_merge(m);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();                             // wpart may still be read from a previous use
+    if (lane == 0) wpart[wv] = m;
+    __syncthreads();
+    Moments r = moments_empty();
+    if (threadIdx.x < SB_WAVE) {
+        if (threadIdx.x < SB_STATS_NT / SB_WAVE) r = wpart[threadIdx.x];
+        r = wave_merge(r);
+    }
+    return r;
+}
+
+// std = 2/sqrt(var/N), r = (max-min)/4 in the working precision
+// ref: generic/sea_breeze_diag.f90:478-479 (N = nlons*nlats, the merged sample count)
+template <typename T>
+__device__ __forceinline__ void sigmoid_scalars(const Moments &m, T *__restrict__ stats) {
+    const T var = (T)m.m2;
+    const T cnt = (T)m.n;
+    stats[0] = T(2) / sqrt(var / cnt);
+    stats[1] = ((T)m.mx - (T)m.mn) / T(4);
+    stats[2] = (T)m.mean;
+    stats[3] = var;
+}
+
+#endif  // __HIPCC__
 
 // Grid geometry shared by every kernel of one call.
 struct Geo {
@@ -91,6 +138,8 @@ struct DiagJob {
     T *nws, *nwd;                   // (nx, ny): this call's wind speed / direction at band cells (k_wind -> k_final)
     int *next_flags;                // the other tile-flag buffer: k_final clears it for the next call
     int next_flags_n;
+    int wind_final;                 // 1: k_wind applies thresholds + state update itself (k_thc2 ran before it and
+                                    //    left thc); 0: k_wind leaves nws/nwd and the contrast kernel applies them
     int t0_fly;                     // 1: k_thc derives t0 from theta,z,sigma while staging; 0: reads the t0 workspace
     T *t0;                          // (nxh, nyh)
     uint64_t *bandbits;             // nyh * nw words: interior cells with |mask| <= maxdist
@@ -99,7 +148,7 @@ struct DiagJob {
     int thc_ty, thc_ntx, thc_nty;   // k_thc tile rows and tile-grid shape (tiles are 64 x thc_ty cells)
     int *tile_nnmax;                // per thc tile: 0 = no band cell; k_prep raises 1, k_thc leaves the largest radius
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
-    long long *stamps;              // diagnostic build (-DSB_STAMPS) only: 8 clock stamps per thc tile
+    long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock stamps per thc tile
 };
 
 __device__ __forceinline__ int sb_bit(const uint64_t *bits, int nw, int X, int Y) {
@@ -109,7 +158,12 @@ __device__ __forceinline__ int sb_bit(const uint64_t *bits, int nw, int X, int Y
 // Fortran MODULO(a, p) for reals as flang evaluates it: fmod, then fold into [0,p) for p > 0.
 template <typename T>
 __host__ __device__ inline T sb_modulo(T a, T p) {
-    T r = fmod(a, p);
+    // fmod is exact, and so are these two cases of it: |a| < p leaves a, and p <= a < 2p is a - p
+    // (Sterbenz); the wind-direction difference of ref :245 always lands in one of them
+    T r;
+    if (p > T(0) && fabs(a) < p) r = a;
+    else if (p > T(0) && a >= p && a < p + p) r = a - p;
+    else r = fmod(a, p);
     if ((a < T(0)) != (p < T(0))) {
         if (r == T(0)) r = -r; else r += p;
     }

@@ -22,48 +22,7 @@
 // ------------------------------------------------------------------------------------
 // moments helpers
 // ------------------------------------------------------------------------------------
-#define STATS_NT 1024
-
-__device__ __forceinline__ Moments wave_merge(Moments m) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Moments o;
-        o.n = __shfl_down(m.n, off);
-        o.mean = __shfl_down(m.mean, off);
-        o.m2 = __shfl_down(m.m2, off);
-        o.mn = __shfl_down(m.mn, off);
-        o.mx = __shfl_down(m.mx, off);
-        m = moments_merge(m, o);
-    }
-    return m;
-}
-
-// merge across the waves of a 1024-thread workgroup; the result is valid in thread 0
-__device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
-    m = wave_merge(m);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();                             // wpart may still be read from a previous use
-    if (lane == 0) wpart[wv] = m;
-    __syncthreads();
-    Moments r = moments_empty();
-    if (threadIdx.x < SB_WAVE) {
-        if (threadIdx.x < STATS_NT / SB_WAVE) r = wpart[threadIdx.x];
-        r = wave_merge(r);
-    }
-    return r;
-}
-
-// std = 2/sqrt(var/N), r = (max-min)/4 in the working precision
-// ref: generic/sea_breeze_diag.f90:478-479 (N = nlons*nlats, the merged sample count)
-template <typename T>
-__device__ __forceinline__ void sigmoid_scalars(const Moments &m, T *__restrict__ stats) {
-    const T var = (T)m.m2;
-    const T cnt = (T)m.n;
-    stats[0] = T(2) / sqrt(var / cnt);
-    stats[1] = ((T)m.mx - (T)m.mn) / T(4);
-    stats[2] = (T)m.mean;
-    stats[3] = var;
-}
+#define STATS_NT SB_STATS_NT
 
 // Shifted sums of one thread -> (n, mean, M2)
 __device__ __forceinline__ Moments moments_from_shifted(double c, double s1, double s2, double mn, double mx,
@@ -180,7 +139,7 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
 //            -> fill value outside the band           ref :176 / seabreeze_diag_python.f90:173,279-280
 // ------------------------------------------------------------------------------------
 template <typename T, int SPT>
-__global__ __launch_bounds__(STATS_NT, 8) void k_scan(DiagJob<T> job, Moments *__restrict__ partials,
+__global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__restrict__ partials,
                                                    int do_stats) {
     const Geo g = job.g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -203,49 +162,55 @@ __global__ __launch_bounds__(STATS_NT, 8) void k_scan(DiagJob<T> job, Moments *_
     const unsigned dY = nwaves / unw, dX = nwaves - dY * unw;
     const unsigned nxh = (unsigned)g.nxh, unx = (unsigned)g.nx;
 
-    for (unsigned s0 = w0; s0 < nseg; s0 += SPT * nwaves) {
-        T sg[SPT], mk[SPT], wsv[SPT], wdv[SPT];
-        unsigned Yq[SPT], Wq[SPT];
+    // One trip = SPT segments.  The loads of the NEXT trip are issued before this trip's values are
+    // used, unconditionally and from clamped addresses: a load under a branch is waited for inside the
+    // branch (one round trip per segment), and a load issued behind this trip's stores would make the
+    // next wait sit out those stores as well (loads and stores share the in-order vmcnt counter).
+    struct Trip {
+        T sg[SPT], mk[SPT], ws[SPT], wd[SPT];
+        unsigned Y[SPT], W[SPT];
+    };
+    auto issue = [&](unsigned s0, Trip &t) {
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const unsigned seg = s0 + q * nwaves;
-            Yq[q] = Yc;
-            Wq[q] = Xc;
+            t.Y[q] = Yc;
+            t.W[q] = Xc;
             const int X = (int)(Xc * 64u) + lane;
             const int xi = X - g.h, yi = (int)Yc - g.h;
             const bool in = seg < nseg && X < g.nxh;
             const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
-            sg[q] = T(0); mk[q] = T(0); wsv[q] = T(0); wdv[q] = T(0);
-            if (in) {
-                const unsigned idx = Yc * nxh + (unsigned)X;
-                mk[q] = job.mask[idx];
-                if (do_stats && interior) sg[q] = job.sigma[idx];
-            }
-            if (wrapper && interior && yi < g.rows) {
-                const unsigned o = (unsigned)yi * unx + (unsigned)xi;
-                wsv[q] = job.ws[o];
-                wdv[q] = job.wd[o];
+            const unsigned idx = in ? Yc * nxh + (unsigned)X : 0u;
+            t.mk[q] = job.mask[idx];
+            t.sg[q] = T(0); t.ws[q] = T(0); t.wd[q] = T(0);
+            if (do_stats) t.sg[q] = job.sigma[idx];                      // wave-uniform condition
+            if (wrapper) {                                               // wave-uniform condition
+                const unsigned o = (interior && yi < g.rows) ? (unsigned)yi * unx + (unsigned)xi : 0u;
+                t.ws[q] = job.ws[o];
+                t.wd[q] = job.wd[o];
             }
             Yc += dY; Xc += dX;
             if (Xc >= unw) { Xc -= unw; Yc += 1; }
         }
+    };
+    auto process = [&](unsigned s0, const Trip &t) {
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const unsigned seg = s0 + q * nwaves;
             if (seg >= nseg) break;                              // wave-uniform
-            const int X = (int)(Wq[q] * 64u) + lane, xi = X - g.h, yi = (int)Yq[q] - g.h;
+            const int X = (int)(t.W[q] * 64u) + lane, xi = X - g.h, yi = (int)t.Y[q] - g.h;
             const bool in = X < g.nxh;
             const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
             if (do_stats && interior) {
-                const double x = (double)sg[q], d = x - c;
+                const double x = (double)t.sg[q], d = x - c;
                 s1 += d;
                 s2 = __builtin_fma(d, d, s2);
                 mn = fmin(mn, x);
                 mx = fmax(mx, x);
                 ++cnt;
             }
-            const bool cls = in && (mk[q] >= T(0));
-            const bool band = interior && yi < g.rows && !(fabs(mk[q]) > job.maxdist);
+            const bool cls = in && (t.mk[q] >= T(0));
+            const bool band = interior && yi < g.rows && !(fabs(t.mk[q]) > job.maxdist);
             const uint64_t wc = __ballot(cls);
             const uint64_t wb = __ballot(band);
             if (lane == 0) {
@@ -254,7 +219,7 @@ __global__ __launch_bounds__(STATS_NT, 8) void k_scan(DiagJob<T> job, Moments *_
             }
             if (wb) {                                            // wave-uniform
                 // the segment straddles two tile columns when the ghost width is not a multiple of 64
-                const int tA = ((int)(Wq[q] * 64u) - g.h) >> 6;
+                const int tA = ((int)(t.W[q] * 64u) - g.h) >> 6;
                 const uint64_t mB = __ballot(band && (xi >> 6) != tA);
                 if (lane == 0) {
                     const int trow = (yi / job.thc_ty) * job.thc_ntx;
@@ -267,11 +232,25 @@ __global__ __launch_bounds__(STATS_NT, 8) void k_scan(DiagJob<T> job, Moments *_
                 if (!wrapper) job.sb_con[o] = job.fill;
                 else {
                     job.out[o] = job.fill;
-                    job.out[2 * pl + o] = wsv[q];
-                    job.out[3 * pl + o] = wdv[q];
+                    job.out[2 * pl + o] = t.ws[q];
+                    job.out[3 * pl + o] = t.wd[q];
                 }
             }
         }
+    };
+    // two register sets, alternating: the loads of trip n+1 are issued before trip n is used
+    const unsigned step = SPT * nwaves;
+    Trip ta, tb;
+    unsigned s0 = w0;
+    if (s0 < nseg) issue(s0, ta);
+    while (s0 < nseg) {
+        if (s0 + step < nseg) issue(s0 + step, tb);              // wave-uniform
+        process(s0, ta);
+        s0 += step;
+        if (s0 >= nseg) break;
+        if (s0 + step < nseg) issue(s0 + step, ta);
+        process(s0, tb);
+        s0 += step;
     }
     if (!do_stats) return;
     __shared__ Moments wpart[STATS_NT / SB_WAVE];
@@ -409,24 +388,30 @@ __global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job) {
     const size_t pl = (size_t)g.nx * g.ny;
     const size_t o = (size_t)y * g.nx + x;
     const int nz = job.nz;
+    // the final update's inputs: issued ahead of the column walk
+    T n_thc = T(0), ws_old = T(0), wd_old = T(0);
+    if (job.wind_final) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
     int lev = 0;
     if (job.flavour == SB_FLAVOUR_GENERIC) {
+        // whole batches of UN levels in flight; the last batch is padded by re-reading level
+        // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
+        // loads follows the batches
         const T *pc = job.p + o;
-        T best = fabs(sb_ld<T, NTL>(pc) - job.target_plev);
-        int k = 1;
-        for (; k + UN <= nz; k += UN) {
+        T best = T(0);
+        for (int k0 = 0; k0 < nz; k0 += UN) {
             T d[UN];
 #pragma unroll
-            for (int q = 0; q < UN; ++q) d[q] = sb_ld<T, NTL>(pc + (size_t)(k + q) * pl);
+            for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q < nz ? k0 + q : nz - 1;
+                d[q] = sb_ld<T, NTL>(pc + (size_t)k * pl);
+            }
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q;
                 const T a = fabs(d[q] - job.target_plev);
-                if (a < best) { best = a; lev = k + q; }
+                if (k == 0) best = a;                            // the search starts at level 1 (ref :223)
+                else if (k < nz && a < best) { best = a; lev = k; }
             }
-        }
-        for (; k < nz; ++k) {
-            const T a = fabs(sb_ld<T, NTL>(pc + (size_t)k * pl) - job.target_plev);
-            if (a < best) { best = a; lev = k; }
         }
     } else {
         T best = fabs(job.p[0] - job.target_plev);
@@ -437,8 +422,16 @@ __global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job) {
     }
     const T uu = job.u[(size_t)lev * pl + o];
     const T vv = job.v[(size_t)lev * pl + o];
-    job.nws[o] = sqrt(uu * uu + vv * vv);                        // ref :225
-    job.nwd[o] = atan2(-uu, -vv) * T(57.2957);                   // ref :227, rad2deg (sic) :128
+    const T n_ws = sqrt(uu * uu + vv * vv);                      // ref :225
+    const T n_wd = atan2(-uu, -vv) * T(57.2957);                 // ref :227, rad2deg (sic) :128
+    if (job.wind_final) {
+        // k_thc2 ran first and left this call's contrast in thc: thresholds, scaling and state
+        // update happen here, under the HBM latency of the column walk   ref :235-266
+        sb_trigger_update<T>(job, o, n_thc, SbCellState<T>{n_ws, n_wd, ws_old, wd_old});
+    } else {
+        job.nws[o] = n_ws;
+        job.nwd[o] = n_wd;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -470,53 +463,75 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     const Geo &g = job.g;
     hipStream_t st = lc.stream;
     hipEvent_t *ev = lc.prof;
-    static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 7;   // tuning knob (diagnostic)
+    static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 8;   // tuning knob (diagnostic)
+    static const bool old_thc = getenv("SB_OLD_THC") != nullptr;                  // k_gz + k_thc instead of k_thc2 (diagnostic)
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
-    // k_wind (HBM gather, SIMDs half idle) next to k_gz/k_thc (issue-bound, little HBM traffic):
-    // with a second stream the two run side by side and a small kernel joins them
-    const bool overlap = lc.aux_stream != nullptr && lc.phases == 3 && job.t0_fly;
+    // the fused second half (k_thc2) exists for LDS halos up to 16; wider windows keep k_gz + k_thc
+    const bool thc2 = H <= 16 && !old_thc;
+    // k_thc2 merges k_scan's moments itself; the f2py flavour needs the scalars earlier, for k_t0
+    const bool merge_in_thc2 = thc2 && job.t0_fly && !gathered;
     hipError_t e = hipSuccess;
+    const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+    int nblk = (int)((nseg + 79) / 80);                          // 16 waves x 5 segments per trip
+    if (nblk < 1) nblk = 1;
+    static const int scan_wgs = getenv("SB_SCAN_WGS") ? atoi(getenv("SB_SCAN_WGS")) : 1;   // tuning knob (diagnostic)
+    if (nblk > scan_wgs * lc.ncu) nblk = scan_wgs * lc.ncu;      // one 1024-thread workgroup per CU, two trips of loads in flight
+    // Single-domain calls on the k_thc2 path run the contrast first and let k_wind apply the
+    // thresholds and the state update (job.wind_final); a band step must run k_scan + k_wind
+    // before its ghost rows arrive, so there k_thc2 applies them.
+    if (job.wind_final && ph2) {
+        if (ev) { (void)hipEventRecord(ev[0], st); }
+        static const int spt0 = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 2;   // tuning knob (diagnostic)
+        if (spt0 <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
+        else if (spt0 <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
+        else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
+        if (!merge_in_thc2)
+            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
+                               (Moments *)nullptr);
+        if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[4], st); }
+        if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+        if (ev) { (void)hipEventRecord(ev[5], st); }
+        if ((e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
+                                   (T *)lc.stats, st)) != hipSuccess) return e;
+        if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[2], st); }
+        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
+        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
+        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job);
+        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
+        if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[7], st); }
+        return hipGetLastError();
+    }
     // ---- phase 1: needs neither theta's ghost cells nor the statistics -----------------------
     if (ph1) {
-        // k_scan (+ merge of the statistics when they are this domain's own)
+        // k_scan (+ merge of the statistics when they are this domain's own and k_thc2 does not do it)
         if (ev) (void)hipEventRecord(ev[0], st);
-        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
-        int nblk = (int)((nseg + 79) / 80);                      // 16 waves x 5 segments per trip
-        if (nblk < 1) nblk = 1;
-        if (nblk > 2 * lc.ncu) nblk = 2 * lc.ncu;                // two workgroups per CU: every wave slot busy
-        static const int spt = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 3;   // tuning knob (diagnostic)
+        static const int spt = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 2;   // tuning knob (diagnostic)
         if (spt <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
         else if (spt <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
         else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
-        if (!gathered) hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk,
-                                          (T *)lc.stats, (Moments *)nullptr);
+        if (!gathered && !merge_in_thc2)
+            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
+                               (Moments *)nullptr);
         if (ev) (void)hipEventRecord(ev[1], st);
         // k_wind
-        hipStream_t sw = st;
-        if (overlap) {
-            sw = lc.aux_stream;
-            if ((e = hipEventRecord(lc.fork, st)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(sw, lc.fork, 0)) != hipSuccess) return e;
-        }
-        if (ev) (void)hipEventRecord(ev[2], sw);
+        if (ev) (void)hipEventRecord(ev[2], st);
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
         static const bool plain = getenv("SB_WIND_PLAIN") != nullptr;   // tuning knob (diagnostic)
-        if (plain) hipLaunchKernelGGL((k_wind<T, 7, false>), wg, wb, 0, sw, job);
-        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, sw, job);
-        else if (un <= 7) hipLaunchKernelGGL((k_wind<T, 7, true>), wg, wb, 0, sw, job);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, sw, job);
-        if (ev) (void)hipEventRecord(ev[3], sw);
-        if (overlap && (e = hipEventRecord(lc.join, sw)) != hipSuccess) return e;
+        if (plain) hipLaunchKernelGGL((k_wind<T, 8, false>), wg, wb, 0, st, job);
+        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
+        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job);
+        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
+        if (ev) (void)hipEventRecord(ev[3], st);
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
         if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
                                          (T *)lc.stats);
         if (ev) (void)hipEventRecord(ev[4], st);
-        // k_t0 (f2py flavour: t0 everywhere) / k_gz (host-model flavour: gz near the band)
+        // k_t0 (f2py flavour: the t0 plane is an output) / k_gz (host-model flavour on the k_thc path only)
         if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-        else {
+        else if (!thc2) {
             const int TY = job.thc_ty;
             // tiles to look at around a tile: the halo H in tile units; one more column at the
             // longitude seam when the last tile column is narrower than a tile
@@ -525,13 +540,12 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
         }
         if (ev) (void)hipEventRecord(ev[5], st);
-        // k_thc: contrast (+ thresholds + state update unless k_wind is still running beside it)
-        if ((e = sb_launch_thc<T>(job, H, lc.ncu, !overlap, st)) != hipSuccess) return e;
+        // contrast, thresholds, state update
+        if (thc2) e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
+                                        (T *)lc.stats, st);
+        else e = sb_launch_thc<T>(job, H, lc.ncu, true, st);
+        if (e != hipSuccess) return e;
         if (ev) (void)hipEventRecord(ev[6], st);
-        if (overlap) {
-            if ((e = hipStreamWaitEvent(st, lc.join, 0)) != hipSuccess) return e;
-            if ((e = sb_launch_final_tiles<T>(job, lc.ncu, st)) != hipSuccess) return e;
-        }
         if (ev) (void)hipEventRecord(ev[7], st);
     }
     return hipGetLastError();

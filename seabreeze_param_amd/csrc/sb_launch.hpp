@@ -17,8 +17,6 @@ struct SbLaunchCtx {
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
     int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
-    hipStream_t aux_stream;         // non-null: run k_wind there, side by side with k_gz/k_thc (fork/join)
-    hipEvent_t fork, join;
     int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics merge, k_t0/k_gz, k_thc.  3 = the whole call
 };
@@ -33,8 +31,10 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
 int sb_thc_tile_rows(int H);                                         // k_thc tiles are 64 x this many cells
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse_final, hipStream_t st);
+// the fused second half (H <= 16): partials/nparts: k_scan's moments to merge (0: read job.stats)
 template <typename T>
-hipError_t sb_launch_final_tiles(const DiagJob<T> &job, int ncu, hipStream_t st);
+hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *partials, int nparts, T *stats_out,
+                          hipStream_t st);
 
 template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st);

@@ -19,13 +19,14 @@
 
 #ifdef SB_STAMPS
 #define SB_STAMP(i) \
-    do { if (threadIdx.x == 0) job.stamps[(size_t)tile * 8 + (i)] = clock64(); } while (0)
+    do { if (threadIdx.x == 0) job.stamps[(size_t)tile * SB_NSTAMP + (i)] = clock64(); } while (0)
 #else
 #define SB_STAMP(i) do { } while (0)
 #endif
 
 #define THC_NT 1024
 #define THC_MAXMINE 256          // active tiles one workgroup can own
+#define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
 
 // ------------------------------------------------------------------------------------
 // Global-memory search for cells whose window outgrows the LDS tile (rare).  Rings are
@@ -35,13 +36,13 @@
 // ------------------------------------------------------------------------------------
 // t0 of one cell of the ghost-celled frame: from the workspace (f2py flavour) or derived on the spot
 template <typename T>
-__device__ __forceinline__ T cell_t0(const DiagJob<T> &job, size_t idx) {
+__device__ __forceinline__ T cell_t0(const DiagJob<T> &job, size_t idx, T sd, T rr) {
     if (!job.t0_fly) return job.t0[idx];
-    return sb_t0<T>(job.theta[idx], job.z[idx], job.sigma[idx], job.stats[0], job.stats[1]);
+    return sb_t0<T>(job.theta[idx], job.z[idx], job.sigma[idx], sd, rr);
 }
 
 template <typename T>
-__device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &nn_used, bool &one_class) {
+__device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, T sd, T rr, int &nn_used, bool &one_class) {
     const Geo g = job.g;
     int X, Y;
     bool has_l = false, has_s = false;
@@ -66,12 +67,12 @@ __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &
     nn_used = nn;
     one_class = !found;
     sb_map_cell(g, x, y, X, Y);
-    const double c0 = (double)cell_t0(job, (size_t)Y * g.nxh + X);
+    const double c0 = (double)cell_t0(job, (size_t)Y * g.nxh + X, sd, rr);
     double sl = 0.0, ss = 0.0, nl = 0.0, ns = 0.0;
     for (int yy = y - nn; yy <= y + nn; ++yy)
         for (int xx = x - nn; xx <= x + nn; ++xx) {
             if (!sb_map_cell(g, xx, yy, X, Y)) continue;
-            const double d = (double)cell_t0(job, (size_t)Y * g.nxh + X) - c0;
+            const double d = (double)cell_t0(job, (size_t)Y * g.nxh + X, sd, rr) - c0;
             if (sb_bit(job.clsbits, g.nw, X, Y)) { sl += d; nl += 1.0; } else { ss += d; ns += 1.0; }
         }
     return (T)(sl / nl - ss / ns);               // 0/0 -> NaN when a class is missing
@@ -85,87 +86,104 @@ __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, int &
 // round-robin to its workgroups: tiles staged at the same time on one XCD are neighbours,
 // and the halo cells they share are fetched from HBM once.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int ntiles, int *s_mine, int *s_wcnt) {
-    constexpr int NT = THC_NT, NWV = THC_NT / SB_WAVE;
+template <int NT = THC_NT>
+__device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int ntiles, int *s_mine, int *s_wcnt,
+                                              unsigned long long *s_mine2) {
+    // s_wcnt: 64 ints, s_mine2: 64 ballot words.  A chunk is K * NT = 64 * 64 tiles whose flags are
+    // all loaded at once (one global round trip per chunk and pass; a single-chunk grid keeps the
+    // flags of the counting pass in registers for the assignment pass).
+    constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;   // K flag loads in flight per thread
+    static_assert(NE <= SB_WAVE, "the count table is prefixed by one wave");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nchunks = (ntiles + K * NT - 1) / (K * NT);
+    bool f[K];
+    // ---- pass A: number of active tiles ------------------------------------------------------
     int total_active = 0;
-    for (int t0i = 0; t0i < ntiles; t0i += NT) {
-        const int t = t0i + tid;
-        const uint64_t bm = __ballot((t < ntiles) && (flags[t] != 0));
-        if (lane == 0) s_wcnt[wv] = __popcll(bm);
-        __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        int v[K];
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) total_active += s_wcnt[w];
+        for (int k = 0; k < K; ++k) {            // loads from clamped addresses, never under a branch:
+            const int t = (ch * K + k) * NT + tid;   // a conditional load is waited for inside its branch
+            v[k] = flags[t < ntiles ? t : ntiles - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            f[k] = (ch * K + k) * NT + tid < ntiles && v[k] != 0;
+            const uint64_t bm = __ballot(f[k]);
+            if (lane == 0) s_wcnt[k * NWV + wv] = __popcll(bm);
+        }
+        __syncthreads();
+        int c = lane < NE ? s_wcnt[lane] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        total_active += c;
         __syncthreads();
     }
     const bool xcd_map = (gridDim.x % 8 == 0);
     const int per = (total_active + 7) / 8, nper = (int)gridDim.x / 8;
-    int base = 0;
-    for (int t0i = 0; t0i < ntiles; t0i += NT) {
-        const int t = t0i + tid;
-        const bool flag = (t < ntiles) && (flags[t] != 0);
-        const uint64_t bm = __ballot(flag);
-        if (lane == 0) s_wcnt[wv] = __popcll(bm);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-            const int cw = s_wcnt[w];
-            before += (w < wv) ? cw : 0;
-            total += cw;
-        }
-        if (flag) {
-            const int pos = base + before + __popcll(bm & ((1ull << lane) - 1ull));
-            int owner, slot;
-            if (xcd_map) {
-                const int xq = pos / per, ii = pos - xq * per;
-                owner = xq + 8 * (ii % nper);
-                slot = ii / nper;
-            } else {
-                owner = pos % (int)gridDim.x;
-                slot = pos / (int)gridDim.x;
-            }
-            if (owner == (int)blockIdx.x && slot < THC_MAXMINE) s_mine[slot] = t;
-        }
-        base += total;
-        __syncthreads();
-    }
+    // how many entries of the row-major list this workgroup owns, and which (position of entry j)
     int nmine;
+    const int xq = (int)blockIdx.x % 8, local = (int)blockIdx.x / 8;
     if (xcd_map) {
-        const int xq = (int)blockIdx.x % 8, local = (int)blockIdx.x / 8;
         int cnt = total_active - xq * per;
         cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
         nmine = cnt > local ? (cnt - 1 - local) / nper + 1 : 0;
     } else {
-        nmine = base > (int)blockIdx.x ? (base - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+        nmine = total_active > (int)blockIdx.x ? (total_active - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     }
-    return nmine > THC_MAXMINE ? THC_MAXMINE : nmine;    // the launcher sizes the grid so this never binds
-}
-
-// ------------------------------------------------------------------------------------
-// k_final_tiles: thresholds, scaling and state update (ref: generic/sea_breeze_diag.f90:
-// 235-266) for the band cells of every active tile, when k_thc ran side by side with k_wind
-// and could not apply them itself.  Same persistent tile walk as k_thc.
-// ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(THC_NT) void k_final_tiles(DiagJob<T> job) {
-    __shared__ int s_mine[THC_MAXMINE];
-    __shared__ int s_wcnt[THC_NT / SB_WAVE];
-    const Geo g = job.g;
-    const int tid = threadIdx.x, TY = job.thc_ty, ntx = job.thc_ntx;
-    const int nmine = thc_build_list(job.tile_nnmax, job.thc_ntx * job.thc_nty, s_mine, s_wcnt);
-    __syncthreads();
-    for (int mi = 0; mi < nmine; ++mi) {
-        const int tile = s_mine[mi];
-        const int x0 = (tile % ntx) * 64, y0 = (tile / ntx) * TY;
-        for (int i = tid; i < 64 * TY; i += THC_NT) {
-            const int x = x0 + (i & 63), y = y0 + (i >> 6);
-            if (x < g.nx && y < g.rows && sb_bit(job.bandbits, g.nw, x + g.h, y + g.h)) {
-                const size_t o = (size_t)y * g.nx + x;
-                sb_trigger_update<T>(job, o, job.thc[o], sb_trigger_load<T>(job, o));
+    nmine = nmine > THC_MAXMINE ? THC_MAXMINE : nmine;   // the launcher sizes the grid so this never binds
+    // ---- pass B: the tile at each of those positions.  Per chunk the ballots of every wave go to LDS;
+    // thread j then finds the (k, wave) entry whose range of positions holds its position and picks
+    // the matching set bit -- no per-tile division or modulo (integer division is a long instruction
+    // sequence, and the old form ran it for every active tile in every workgroup).
+    uint64_t *s_bm = (uint64_t *)s_mine2;                // NE ballot words, 8-byte aligned by the caller
+    int base = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (nchunks > 1) {
+            int v[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int t = (ch * K + k) * NT + tid;
+                v[k] = flags[t < ntiles ? t : ntiles - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) f[k] = (ch * K + k) * NT + tid < ntiles && v[k] != 0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint64_t bm = __ballot(f[k]);
+            if (lane == 0) { s_wcnt[k * NWV + wv] = __popcll(bm); s_bm[k * NWV + wv] = bm; }
+        }
+        __syncthreads();
+        // inclusive prefix of the NE counts (tile order: k major, then wave)
+        const int c = lane < NE ? s_wcnt[lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < SB_WAVE; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int chunk_total = __shfl(incl, SB_WAVE - 1);
+        // wave 0: lane e knows the range [base + incl - c, base + incl) of entry e
+        if (wv == 0) {
+            for (int j = 0; j < nmine; ++j) {
+                const int pos = xcd_map ? xq * per + local + j * nper : (int)blockIdx.x + j * (int)gridDim.x;
+                const int rel = pos - base;
+                const uint64_t hit = __ballot(lane < NE && rel >= incl - c && rel < incl);
+                if (hit) {                                       // wave-uniform: the position lies in this chunk
+                    const int e = __ffsll((unsigned long long)hit) - 1;
+                    const int nth = rel - (__shfl(incl, e) - __shfl(c, e));   // which set bit of that ballot
+                    uint64_t bm = s_bm[e];
+                    for (int i = 0; i < nth; ++i) bm &= bm - 1;   // drop the nth lowest set bits (nth < 64)
+                    const int bit = __ffsll((unsigned long long)bm) - 1;
+                    if (lane == 0) s_mine[j] = (ch * K + e / NWV) * NT + (e % NWV) * SB_WAVE + bit;
+                }
             }
         }
+        base += chunk_total;
+        __syncthreads();
     }
+    return nmine;
 }
 
 template <typename T, int TY, int H, bool FLY, bool FUSE>
@@ -183,14 +201,15 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
     __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
     __shared__ int s_mine[THC_MAXMINE];
-    __shared__ int s_wcnt[NWV];
+    __shared__ int s_wcnt[SB_WAVE];
     __shared__ int s_nn;
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
 
-    int nmine = thc_build_list(job.tile_nnmax, ntiles, s_mine, s_wcnt);
+    __shared__ unsigned long long s_bmw[SB_WAVE];
+    int nmine = thc_build_list(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw);
     for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
     const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
                 if (g.bnd == BND_HALO)
                     cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
                 bool one_class;
-                contrast = contrast_global(job, x, y, cap, nn, one_class);
+                contrast = contrast_global(job, x, y, cap, job.t0_fly ? job.stats[0] : T(0), job.t0_fly ? job.stats[1] : T(0), nn, one_class);
                 atomicAdd(&job.counters[0], 1);
                 if (one_class) atomicAdd(&job.counters[1], 1);
             }
@@ -448,10 +467,568 @@ __global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
     }
 }
 
+
+// ====================================================================================
+// k_thc2: the whole second half of a diag call in one persistent launch (halo H <= 16):
+// sigmoid scalars (merge of k_scan's moments), t0 = theta - (gmma*z)*sigmoid(sigma) on the
+// fly, the three summed-area tables, the radius search, thresholds and state update.
+//
+// Per tile the work is laid out so that nothing waits on HBM and no LDS pass is serial:
+//   T0  band cells of the tile compacted into a list (full waves in the search however
+//       ragged the band is); their state / wind loads are issued now
+//   T1  the tile's inputs -- prefetched into registers while the PREVIOUS tile was being
+//       processed -- become t0 - c0; a wave owns RPW consecutive rows, so the prefix along
+//       latitude inside its band is RPW register adds per column, the land-side count is
+//       prefixed along the row with ballot + popcount, and each wave leaves the column
+//       totals of its band; then the NEXT tile's loads are issued
+//   T2  exclusive prefix of the 16 band totals of every column (3*W short tasks)
+//   T3  prefix along longitude: 8 threads per row, each a 12-cell run, run totals combined
+//       by an 8-lane shuffle scan; the band offsets of T2 are added on the way in
+//   T4  bisection on the count table, contrast from the two fp64 tables, thresholds,
+//       state update (ref: generic/sea_breeze_diag.f90:188-216, :235-266)
+// The barriers between the phases wait for LDS traffic only (lds_barrier), so the
+// prefetched global loads stay in flight across them.
+// ====================================================================================
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the 64 bits of `bits` for the interior cells (x0 .. x0+63, y): at most two words of the plane
+__device__ __forceinline__ uint64_t tile_row_bits(const uint64_t *__restrict__ bits, const Geo &g, int x0, int y) {
+    const int X = x0 + g.h, Y = y + g.h;
+    const int wi = X >> 6, sh = X & 63;
+    const uint64_t *row = bits + (size_t)Y * g.nw;
+    uint64_t w = row[wi] >> sh;
+    if (sh && wi + 1 < g.nw) w |= row[wi + 1] << (64 - sh);
+    return w;
+}
+
+// everything a thread holds of a tile between the issue of its loads and T1
+template <typename T, int NC, int NCH, bool FLY>
+struct ThcRegs {
+    T th[NC];                      // theta (FLY) or t0
+    T zz[FLY ? NC : 1], sg[FLY ? NC : 1];
+    uint32_t lw[NC];               // the 32-bit half of the land-side word that holds the cell
+    int xcol[NCH];                 // array column of each chunk, -1: no such cell
+    unsigned okm;                  // bit k: cell k exists
+    uint64_t bw0, bw1;             // the two words that hold the band bits of tile row tid (tid < TY)
+    int bsh;                       // their shift, -1: no such row
+    T c0;                          // the tile's offset
+};
+
+template <typename T, int TY, int H, bool FLY, int RPW, int NCH>
+__device__ __forceinline__ void thc2_issue(const DiagJob<T> &job, int tile, ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+    constexpr int TX = 64, W = TX + 2 * H;
+    const Geo g = job.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntx = job.thc_ntx;
+    const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
+    int X, Y;
+    sb_map_cell(g, x0, y0, X, Y);
+    const unsigned unxh = (unsigned)g.nxh;
+    const unsigned i00 = (unsigned)Y * unxh + (unsigned)X;
+    const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * SB_WAVE + lane;
+        const int xs = x0 - H + c;
+        bool ok = c < W;
+        int Xc = 0;
+        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
+        else if (fastx) {
+            if (g.bnd == BND_WRAPPER) {
+                int m = xs + 1;
+                m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
+                Xc = (m < 1 ? 1 : m) - 1;
+            } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
+        } else {
+            int Yd;
+            sb_map_cell(g, xs, y0, Xc, Yd);
+        }
+        R.xcol[ch] = ok ? Xc : -1;
+    }
+    R.okm = 0;
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+        const int r = wv * RPW + ri;
+        const int ys = y0 - H + r;
+        int Yr;
+        bool rowok = true;
+        if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
+        else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+        const unsigned rowbase = (unsigned)Yr * unxh;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int k = ri * NCH + ch;
+            const bool ok = rowok && R.xcol[ch] >= 0;
+            const unsigned ii = ok ? rowbase + (unsigned)R.xcol[ch] : i00;     // i00: any cell that exists
+            if constexpr (FLY) { R.th[k] = job.theta[ii]; R.zz[k] = job.z[ii]; }
+            else R.th[k] = job.t0[ii];
+            R.okm |= (ok ? 1u : 0u) << k;
+        }
+    }
+    // Last, with no control flow behind them (a join would wait for them): the tile's offset -- any
+    // common value conditions the sums, and theta at the tile origin needs no sigmoid -- and the band
+    // words.  Every load of the tile is unconditional, from a clamped address: a load under a branch is
+    // waited for inside the branch, one round trip after the other.
+    if constexpr (FLY) R.c0 = job.theta[i00];
+    else R.c0 = job.t0[i00];
+    {
+        const bool have = tid < TY && y0 + tid < g.rows;
+        const int Xb = x0 + g.h, wi = Xb >> 6;
+        const uint64_t *row = job.bandbits + (size_t)((have ? y0 + tid : y0) + g.h) * g.nw;
+        R.bw0 = row[wi];
+        R.bw1 = row[wi + 1 < g.nw ? wi + 1 : wi];
+        R.bsh = have ? (Xb & 63) + (wi + 1 < g.nw ? 0 : 64) : -1;      // +64: there is no second word
+    }
+}
+
+// The second, late part of a tile's loads: sigma and the land-side words.  Issued when the tile's
+// turn starts (theta and z have been in flight since the previous tile's T1), so that the
+// registers they land in are not live during the previous tile's search.
+template <typename T, int TY, int H, bool FLY, int RPW, int NCH>
+__device__ __forceinline__ void thc2_issue_late(const DiagJob<T> &job, int tile, ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+    const Geo g = job.g;
+    const int wv = threadIdx.x >> 6;
+    const int y0 = (tile / job.thc_ntx) * TY;
+    const uint32_t *cls32 = (const uint32_t *)job.clsbits;
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) {
+        const int ys = y0 - H + wv * RPW + ri;
+        int Yr;
+        if (g.bnd == BND_HALO) { Yr = ys + g.h; Yr = (Yr >= 0 && Yr < g.nyh) ? Yr : 0; }
+        else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+        const unsigned rowbase = (unsigned)Yr * (unsigned)g.nxh, wordbase = (unsigned)Yr * (unsigned)g.nw;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int k = ri * NCH + ch;
+            const unsigned xc = ((R.okm >> k) & 1u) ? (unsigned)R.xcol[ch] : 0u;    // unconditional, clamped
+            if constexpr (FLY) R.sg[k] = job.sigma[rowbase + xc];
+            R.lw[k] = cls32[(size_t)(wordbase + (xc >> 6)) * 2 + ((xc >> 5) & 1u)];
+        }
+    }
+}
+
+template <typename T, int TY, int H, bool FLY>
+__global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments *__restrict__ partials, int nparts,
+                                                  T *__restrict__ stats_out) {
+    constexpr int TX = 64, NT = THC2_NT, NWV = NT / SB_WAVE;
+    constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
+    constexpr int RPW = HT / NWV;                // consecutive table rows a wave owns
+    constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;
+    constexpr int NC = RPW * NCH;
+    constexpr int NSEG = 8, SEG = W / NSEG;      // the longitude prefix: 8 runs of SEG cells per row
+    constexpr int CPT = (TX * TY + NT - 1) / NT; // list entries per thread in the search
+    static_assert(HT % NWV == 0, "every wave owns the same number of rows");
+    static_assert(W % NSEG == 0 && (2 * HT * NSEG) % SB_WAVE == 0, "row-pass task shape");
+    static_assert(TY <= SB_WAVE && TY <= NT && NC <= 32, "tile shape");
+    static_assert((size_t)W * HT < 65536, "u16 count table");
+    __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
+    __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
+    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
+    __shared__ double pA[NWV * W], pL[NWV * W];  // per-wave band totals of every column -> exclusive prefix
+    __shared__ int pC[NWV * W];
+    __shared__ int s_mine[THC_MAXMINE];
+    __shared__ int s_wcnt[SB_WAVE];
+    __shared__ uint64_t s_word[TY];
+    __shared__ unsigned short s_cell[TX * TY];
+    __shared__ Moments s_wpart[SB_STATS_NT / SB_WAVE];
+    __shared__ T s_stats[4];
+    __shared__ unsigned long long s_bmw[SB_WAVE];
+    __shared__ unsigned short s_glob[TX * TY];   // cells whose window outgrows the tile (rare): handled after T4
+    __shared__ int s_nglob;
+
+    const Geo g = job.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
+
+#ifdef SB_STAMPS
+    const long long t_begin = clock64(), w_begin = wall_clock64();
+    long long t_pro[6] = {0, 0, 0, 0, 0, 0};
+#define SB_PSTAMP(i) t_pro[i] = clock64() - t_begin
+#else
+#define SB_PSTAMP(i) do { } while (0)
+#endif
+    // k_scan's per-workgroup moments: loaded first, they land while the tile list is built
+    constexpr int NPM = SB_STATS_NT / NT;
+    Moments pm[NPM];
+#pragma unroll
+    for (int j = 0; j < NPM; ++j) {
+        pm[j] = moments_empty();
+        if constexpr (FLY) {
+            if (nparts > 0) {              // wave-uniform; the load itself is unconditional (clamped)
+                const int b = tid + j * NT;
+                const Moments ld = partials[b < nparts ? b : nparts - 1];
+                if (b < nparts) pm[j] = ld;
+            }
+        }
+    }
+    SB_PSTAMP(0);
+    const int nmine = thc_build_list<NT>(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw);
+#ifdef SB_STAMPS
+    const long long t_list = clock64();
+#endif
+    ThcRegs<T, NC, NCH, FLY> R;
+    if (nmine > 0) thc2_issue<T, TY, H, FLY, RPW, NCH>(job, s_mine[0], R);
+    SB_PSTAMP(1);
+    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
+    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+    // sigmoid scalars: merged here from k_scan's per-workgroup moments, in the fixed order and
+    // tree of k_moments_final, so every workgroup (and that kernel) gets the same bits
+    SB_PSTAMP(2);
+    T sd = T(0), rr = T(0);
+    if constexpr (FLY) {
+        if (nparts > 0) {
+            // thread t stands for the threads t, t + NT, ... of that kernel's 1024; each of them is
+            // reduced over its wave, the 16 wave results by the first wave
+#pragma unroll
+            for (int j = 0; j < NPM; ++j) {
+                const int v = tid + j * NT;
+                Moments mv = pm[j];
+                if (j * NT < nparts) {         // wave-uniform; merging empties is the identity, so skip it
+                    for (int b = v + SB_STATS_NT; b < nparts; b += SB_STATS_NT) mv = moments_merge(mv, partials[b]);
+                    mv = wave_merge(mv);
+                }
+                if (lane == 0) s_wpart[v >> 6] = mv;
+            }
+            SB_PSTAMP(3);
+            __syncthreads();
+            SB_PSTAMP(4);
+            Moments m = moments_empty();
+            if (tid < SB_WAVE) {
+                if (tid < SB_STATS_NT / SB_WAVE) m = s_wpart[tid];
+                m = wave_merge(m);
+            }
+            if (tid == 0) {
+                sigmoid_scalars<T>(m, s_stats);
+                if (blockIdx.x == 0 && stats_out) sigmoid_scalars<T>(m, stats_out);
+            }
+            __syncthreads();
+            sd = s_stats[0];
+            rr = s_stats[1];
+        } else {
+            sd = job.stats[0];
+            rr = job.stats[1];
+        }
+    }
+    __syncthreads();
+
+#ifdef SB_STAMPS
+    if (tid == 0 && nmine > 0) {       // prologue of this workgroup, kept with its first tile
+        long long *st = job.stamps + (size_t)s_mine[0] * SB_NSTAMP;
+        st[8] = w_begin;                       // 100 MHz wall clock at this workgroup's first instruction
+        st[9] = clock64() - t_begin;           // whole prologue, shader cycles
+        st[10] = t_list - t_begin;             // tile list
+        for (int i = 0; i < 6; ++i) st[16 + i] = t_pro[i];
+    }
+    if (lane == 0 && nmine > 0 && wv == NWV - 1)   // when did the last wave of the workgroup start?
+        job.stamps[(size_t)s_mine[0] * SB_NSTAMP + 12] = w_begin;
+#endif
+    for (int mi = 0; mi < nmine; ++mi) {
+        const int tile = s_mine[mi];
+        const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
+        SB_STAMP(0);
+        // ---- T0: compact the tile's band cells, issue their state loads ----------------------
+        if (tid < TY) {
+            uint64_t w = 0;
+            if (R.bsh >= 0) {
+                const int sh = R.bsh & 63;
+                w = R.bw0 >> sh;
+                if (sh && R.bsh < 64) w |= R.bw1 << (64 - sh);
+            }
+            s_word[tid] = w;
+        }
+        if (tid == 0) s_nglob = 0;
+        SB_STAMP(24);
+        thc2_issue_late<T, TY, H, FLY, RPW, NCH>(job, tile, R);     // sigma, land-side words: land under T0
+        SB_STAMP(25);
+        lds_barrier();
+        SB_STAMP(26);
+        int total;
+        {
+            const int pc = lane < TY ? __popcll(s_word[lane]) : 0;
+            int incl = pc;
+#pragma unroll
+            for (int d = 1; d < SB_WAVE; d <<= 1) {
+                const int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            total = __shfl(incl, SB_WAVE - 1);
+            const int excl = incl - pc;
+            for (int r = wv; r < TY; r += NWV) {
+                const uint64_t w = s_word[r];
+                const int off = __shfl(excl, r);
+                if ((w >> lane) & 1ull)
+                    s_cell[off + __popcll(w & ((1ull << lane) - 1ull))] = (unsigned short)((r << 6) | lane);
+            }
+        }
+        lds_barrier();
+        SB_STAMP(27);
+        int cq[CPT];
+        uint32_t ownw[CPT];            // the half-word of the land-side plane that holds the cell itself
+        SbCellState<T> cst[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int i = tid + q * NT;
+            cq[q] = i < total ? (int)s_cell[i] : -1;
+            cst[q] = SbCellState<T>{T(0), T(0), T(0), T(0)};
+            {   // unconditional loads; a thread without a cell reads the tile's first cell
+                const int cc = cq[q] >= 0 ? cq[q] : 0;
+                const int x = x0 + (cc & 63), y = y0 + (cc >> 6);
+                if (!job.wind_final) cst[q] = sb_trigger_load<T>(job, (size_t)y * g.nx + x);   // wave-uniform branch
+                const unsigned X = (unsigned)(x + g.h);
+                ownw[q] = ((const uint32_t *)job.clsbits)[((size_t)(y + g.h) * g.nw + (X >> 6)) * 2 + ((X >> 5) & 1u)];
+            }
+        }
+        SB_STAMP(1);
+        // ---- T1: registers -> band-local column prefix -> LDS; band totals ---------------------
+        {
+            const double c0 = (double)R.c0;
+            double runA[NCH], runL[NCH];
+            int runC[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) { runA[ch] = 0.0; runL[ch] = 0.0; runC[ch] = 0; }
+#pragma unroll
+            for (int ri = 0; ri < RPW; ++ri) {
+                const int r = wv * RPW + ri;
+                unsigned carryC = 0;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = ri * NCH + ch;
+                    const int c = ch * SB_WAVE + lane;
+                    const bool ok = (R.okm >> k) & 1u;
+                    const int land = ok ? (int)((R.lw[k] >> (R.xcol[ch] & 31)) & 1u) : 0;
+                    T t0v = R.th[k];
+                    if constexpr (FLY) t0v = sb_t0<T>(R.th[k], R.zz[k], R.sg[k], sd, rr);   // ref :166-167
+                    const double d = ok ? (double)t0v - c0 : 0.0;
+                    const uint64_t lm = __ballot(land);
+                    const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
+                    carryC += (unsigned)__popcll(lm);
+                    runA[ch] += d;
+                    runL[ch] += land ? d : 0.0;
+                    runC[ch] += (int)cn;
+                    if (c < W) {
+                        const int o = (r + 1) * P + c + 1;
+                        sA[o] = runA[ch];
+                        sL[o] = runL[ch];
+                        sC[o] = (unsigned short)runC[ch];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = ch * SB_WAVE + lane;
+                if (c < W) { pA[wv * W + c] = runA[ch]; pL[wv * W + c] = runL[ch]; pC[wv * W + c] = runC[ch]; }
+            }
+        }
+        // the cells' own class, out of the words loaded in T0: resolved here so that nothing loaded
+        // before the prefetch is first used after it (that use would wait for the whole prefetch)
+        unsigned ownbits = 0;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int cc = cq[q] >= 0 ? cq[q] : 0;
+            ownbits |= ((ownw[q] >> ((x0 + (cc & 63) + g.h) & 31)) & 1u) << q;
+        }
+        asm volatile("" : "+v"(ownbits));        // materialise here: the compiler would sink this into T4
+        // the next tile's loads fly under T2..T4 (and under the other workgroups' staging)
+        if (mi + 1 < nmine) thc2_issue<T, TY, H, FLY, RPW, NCH>(job, s_mine[mi + 1], R);
+        lds_barrier();
+        SB_STAMP(2);
+        // ---- T2: exclusive prefix of the band totals along latitude ------------------------------
+        for (int t = tid; t < 3 * W; t += NT) {
+            const int a = t / W, c = t - a * W;
+            if (a < 2) {
+                double *pp = (a == 0 ? pA : pL) + c;
+                double x[NWV];
+#pragma unroll
+                for (int b = 0; b < NWV; ++b) x[b] = pp[b * W];
+                double e = 0.0;
+#pragma unroll
+                for (int b = 0; b < NWV; ++b) { pp[b * W] = e; e += x[b]; }
+            } else {
+                int *pp = pC + c;
+                int x[NWV];
+#pragma unroll
+                for (int b = 0; b < NWV; ++b) x[b] = pp[b * W];
+                int e = 0;
+#pragma unroll
+                for (int b = 0; b < NWV; ++b) { pp[b * W] = e; e += x[b]; }
+            }
+        }
+        lds_barrier();
+        SB_STAMP(3);
+        // ---- T3: prefix along longitude (+ band offsets); count table: band offsets only ---------
+        // 16 consecutive lanes take 16 consecutive rows of one run (the pitch is odd, so their 8-byte
+        // elements fall in 16 different bank pairs); the four 16-lane groups of a wave and the two
+        // tasks of a thread cover the 8 runs of those rows, in an order that also keeps the two
+        // groups of a 32-lane read apart (runs 0,4 | 1,5 and 2,6 | 3,7 for 12-cell runs)
+        {
+            static_assert((2 * HT) % 16 == 0 && NSEG == 8, "row-pass lane mapping");
+            constexpr int NRG = 2 * HT / 16;         // 16-row groups over both fp64 tables
+            const int grp = lane >> 4;
+            for (int rg = wv; rg < NRG; rg += NWV) {
+                const int trow = rg * 16 + (lane & 15);          // row over both tables
+                const int a = trow / HT, row = trow - a * HT;
+                double *trw = (a == 0 ? sA : sL) + (row + 1) * P + 1;
+                const double *orw = (a == 0 ? pA : pL) + (row / RPW) * W;
+                const int sg0 = (grp >> 1) + ((grp & 1) << 2);   // 0,4,1,5
+                const int sg1 = sg0 + 2;                         // 2,6,3,7
+                double v0[SEG], v1[SEG], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) {
+                    v0[i] = trw[sg0 * SEG + i] + orw[sg0 * SEG + i];
+                    v1[i] = trw[sg1 * SEG + i] + orw[sg1 * SEG + i];
+                }
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) { s0 += v0[i]; v0[i] = s0; s1 += v1[i]; v1[i] = s1; }
+                // totals of the 8 runs of this row, in run order, then the exclusive offsets
+                double tot[NSEG];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int src = (lane & 15) + 16 * q;        // group q holds runs (q>>1)+4*(q&1) and that + 2
+                    const int r0 = (q >> 1) + ((q & 1) << 2);
+                    tot[r0] = __shfl(s0, src);
+                    tot[r0 + 2] = __shfl(s1, src);
+                }
+                double e0 = 0.0, e1 = 0.0, acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < NSEG; ++r) {
+                    if (r == sg0) e0 = acc;
+                    if (r == sg1) e1 = acc;
+                    acc += tot[r];
+                }
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) {
+                    trw[sg0 * SEG + i] = v0[i] + e0;
+                    trw[sg1 * SEG + i] = v1[i] + e1;
+                }
+            }
+            for (int task = tid; task < HT * NSEG; task += NT) {
+                const int row = (task & 15) + 16 * (task / (16 * NSEG)), seg = (task >> 4) & (NSEG - 1);
+                unsigned short *tab = sC + (row + 1) * P + 1 + seg * SEG;
+                const int *off = pC + (row / RPW) * W + seg * SEG;
+#pragma unroll
+                for (int i = 0; i < SEG; ++i) tab[i] = (unsigned short)((int)tab[i] + off[i]);
+            }
+        }
+        lds_barrier();
+        SB_STAMP(4);
+        // ---- T4: smallest radius whose square holds both classes (bisection), contrast, update ---
+        // Branch-free up to the final store: a thread without a cell probes around the tile's first
+        // cell and discards the result (divergent control flow costs more in exec-mask bookkeeping
+        // than the probes it would skip).
+        int nnmax = 0;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const bool valid = cq[q] >= 0;
+            const int cc = valid ? cq[q] : 0;
+            const int lx = cc & 63, ly = cc >> 6;
+            const int x = x0 + lx, y = y0 + ly;
+            const int cx = lx + H, cy = ly + H;
+            int lim = H;
+            if (g.bnd == BND_HALO)                               // wave-uniform
+                lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
+            const int limc = max(lim, 1);
+            // land-side cells in the square of radius rad around the cell
+            auto count = [&](int rad) {
+                const int r0 = (cy - rad) * P, r1 = (cy + rad + 1) * P;
+                const int a0 = cx - rad, a1 = cx + rad + 1;
+                return (int)sC[r1 + a1] - (int)sC[r0 + a1] - (int)sC[r1 + a0] + (int)sC[r0 + a0];
+            };
+            int nlq = count(limc);
+            const bool fnd = valid && lim >= 1 && nlq > 0 && nlq < (2 * limc + 1) * (2 * limc + 1);
+            int lo = fnd ? 1 : limc, hi = limc;                  // nothing to bisect unless the widest square is mixed
+            constexpr int ITER = (H <= 2 ? 1 : H <= 4 ? 2 : H <= 8 ? 3 : H <= 16 ? 4 : 5);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int nl = count(mid);
+                const bool act = lo < hi, ok = nl > 0 && nl < (2 * mid + 1) * (2 * mid + 1);
+                nlq = (act && ok) ? nl : nlq;
+                hi = (act && ok) ? mid : hi;
+                lo = (act && !ok) ? mid + 1 : lo;
+            }
+            const int nn = hi;
+            const int r0 = (cy - nn) * P, r1 = (cy + nn + 1) * P;
+            const int a0 = cx - nn, a1 = cx + nn + 1;
+            const int area = (2 * nn + 1) * (2 * nn + 1);
+            const double RL = (sL[r1 + a1] - sL[r0 + a1]) - (sL[r1 + a0] - sL[r0 + a0]);
+            const double RA = (sA[r1 + a1] - sA[r0 + a1]) - (sA[r1 + a0] - sA[r0 + a0]);
+            const T contrast = (T)(RL / (double)nlq - (RA - RL) / (double)(area - nlq));
+            // the cell's own class (not the table's: the f2py boundary rule maps the centre of the
+            // window at the last longitude to column 1)   ref :182-186, seabreeze_diag_python.f90:202
+            const T mul = ((ownbits >> q) & 1u) ? T(1) : T(-1);
+            if (fnd) {
+                nnmax = max(nnmax, nn);
+                if (job.wind_final) job.thc[(size_t)y * g.nx + x] = mul * contrast;        // ref :216; k_wind applies :235-266
+                else sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);   // ref :216, :235-266
+            } else if (valid) {                  // the window outgrows the tile: queue the cell
+                s_glob[atomicAdd(&s_nglob, 1)] = (unsigned short)cc;
+            }
+        }
+        // ---- cells on the global-memory path (none on a grid whose halo hint holds) ---------------
+        lds_barrier();
+        {
+            const int nglob = s_nglob;
+#pragma unroll 1
+            for (int i = tid; i < nglob; i += NT) {
+                const int cc = s_glob[i];
+                const int x = x0 + (cc & 63), y = y0 + (cc >> 6);
+                const size_t o = (size_t)y * g.nx + x;
+                int cap = g.nx + g.ny;
+                if (g.bnd == BND_HALO)
+                    cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
+                bool one_class;
+                int nn;
+                const T contrast = contrast_global(job, x, y, cap, sd, rr, nn, one_class);
+                atomicAdd(&job.counters[0], 1);
+                if (one_class) atomicAdd(&job.counters[1], 1);
+                nnmax = max(nnmax, nn);
+                const T mul = sb_bit(job.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
+                if (job.wind_final) job.thc[o] = mul * contrast;
+                else sb_trigger_update<T>(job, o, mul * contrast, sb_trigger_load<T>(job, o));
+            }
+        }
+        // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters); the flag k_scan
+        // raised is 1, and a nonzero flag stays nonzero for workgroups still building their list
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nnmax = max(nnmax, __shfl_xor(nnmax, off));
+        if (lane == 0 && nnmax > 1) atomicMax(&job.tile_nnmax[tile], nnmax);
+        SB_STAMP(5);
+        // no barrier here: the next tile's T0 touches only s_word / s_cell / s_nglob (all read before
+        // the barrier above), and its two barriers stand between this search and the next table write
+    }
+#ifdef SB_STAMPS
+    if (tid == 0 && nmine > 0) job.stamps[(size_t)s_mine[0] * SB_NSTAMP + 11] = wall_clock64();
+#endif
+}
+
+template <typename T, int TY, int H>
+static void launch_thc2(const DiagJob<T> &job, int nblocks, const Moments *partials, int nparts, T *stats_out,
+                        hipStream_t st) {
+    if (job.t0_fly)
+        hipLaunchKernelGGL((k_thc2<T, TY, H, true>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
+    else
+        hipLaunchKernelGGL((k_thc2<T, TY, H, false>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
+}
+
+template <typename T>
+hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *partials, int nparts, T *stats_out,
+                          hipStream_t st) {
+    const int ntiles = job.thc_ntx * job.thc_nty;
+    int nblocks = ncu;
+    while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
+    if (H <= 8) launch_thc2<T, 32, 8>(job, nblocks, partials, nparts, stats_out, st);
+    else launch_thc2<T, 32, 16>(job, nblocks, partials, nparts, stats_out, st);
+    return hipGetLastError();
+}
+template hipError_t sb_launch_thc2<float>(const DiagJob<float> &, int, int, const Moments *, int, float *, hipStream_t);
+template hipError_t sb_launch_thc2<double>(const DiagJob<double> &, int, int, const Moments *, int, double *, hipStream_t);
+
 template <typename T, int TY, int H>
 static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_t st) {
-    if (job.t0_fly && fuse) hipLaunchKernelGGL((k_thc<T, TY, H, true, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
-    else if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true, false>), dim3(nblocks), dim3(THC_NT), 0, st, job);
+    (void)fuse;
+    if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
     else hipLaunchKernelGGL((k_thc<T, TY, H, false, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
 }
 
@@ -468,17 +1045,6 @@ hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse, hipSt
     else launch_thc<T, 16, 24>(job, nblocks, fuse, st);
     return hipGetLastError();
 }
-
-template <typename T>
-hipError_t sb_launch_final_tiles(const DiagJob<T> &job, int ncu, hipStream_t st) {
-    const int ntiles = job.thc_ntx * job.thc_nty;
-    int nblocks = ncu;
-    while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
-    hipLaunchKernelGGL(k_final_tiles<T>, dim3(nblocks), dim3(THC_NT), 0, st, job);
-    return hipGetLastError();
-}
-template hipError_t sb_launch_final_tiles<float>(const DiagJob<float> &, int, hipStream_t);
-template hipError_t sb_launch_final_tiles<double>(const DiagJob<double> &, int, hipStream_t);
 
 template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, bool, hipStream_t);
 template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, bool, hipStream_t);

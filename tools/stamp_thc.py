@@ -26,20 +26,41 @@ state = [np.zeros((ny, nx), dt) for _ in range(4)]
 for tn in (1, 2):
     ctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *state)
 nt_max = 1 << 16
-buf = (C.c_longlong * (nt_max * 8))()
+NS = 32
+buf = (C.c_longlong * (nt_max * NS))()
 n = C.c_int(0)
 rc = ctx.lib.sb_debug_stamps(ctx.h, buf, C.c_int(nt_max), C.byref(n))
 assert rc == 0, rc
-s = np.frombuffer(buf, dtype=np.int64)[: n.value * 8].reshape(n.value, 8)
+s = np.frombuffer(buf, dtype=np.int64)[: n.value * NS].reshape(n.value, NS)
 LAST = 5
 active = s[:, LAST] != 0
 print(f"tiles {n.value}, active {int(active.sum())}")
-names = ["loads->LDS", "lon scan", "lat scan", "search+store"]
-idx = [0, 1, 2, 3, 5]
+if "SB_OLD_THC" in __import__("os").environ:
+    names, idx = ["loads->LDS", "lon scan", "lat scan", "search+store"], [0, 1, 2, 3, 5]
+else:       # k_thc2
+    names, idx = ["T0 compact", "T1 regs->LDS", "T2 band prefix", "T3 lon prefix", "T4 search"], [0, 1, 2, 3, 4, 5]
 a = s[active]
 for i, nm in enumerate(names):
     d = a[:, idx[i + 1]] - a[:, idx[i]]
     print(f"  {nm:14s} mean {d.mean():9.0f} cyc   median {np.median(d):9.0f}   max {d.max():9.0f}")
+first = a[a[:, 9] != 0]
+if len(first):
+    w0 = first[:, 8].min()
+    print(f"  prologue per workgroup ({len(first)}): list build mean {first[:, 10].mean():.0f} cyc, whole prologue mean "
+          f"{first[:, 9].mean():.0f}, max {first[:, 9].max()}")
+    print(f"  wall clock (10 ns ticks): workgroup starts spread over {first[:, 8].max() - w0}, last wave of a workgroup "
+          f"starts {np.mean(first[:, 12] - first[:, 8]):.0f} after its first (max {np.max(first[:, 12] - first[:, 8])}); "
+          f"workgroup life mean {np.mean(first[:, 11] - first[:, 8]):.0f}, kernel span {first[:, 11].max() - w0}")
+    print("  prologue stamps (cycles since start): before list %.0f, list+first issue %.0f, zeroed %.0f, wave merges %.0f, "
+          "after barrier %.0f" % tuple(first[:, 16 + i].mean() for i in range(5)))
+    print("  T0 split: s_word %.0f, late issue %.0f, barrier %.0f, compaction+barrier %.0f, cell/state loads %.0f" % (
+        (a[:, 24] - a[:, 0]).mean(), (a[:, 25] - a[:, 24]).mean(), (a[:, 26] - a[:, 25]).mean(),
+        (a[:, 27] - a[:, 26]).mean(), (a[:, 1] - a[:, 27]).mean()))
+    rest = a[a[:, 9] == 0]
+    for nm, grp in (("first tile of a workgroup", first), ("later tiles", rest)):
+        if len(grp):
+            ph = [f"{(grp[:, idx[i + 1]] - grp[:, idx[i]]).mean():.0f}" for i in range(len(names))]
+            print(f"  {nm}: phases {ph} total {(grp[:, LAST] - grp[:, 0]).mean():.0f}")
 tot = a[:, LAST] - a[:, 0]
 print(f"  {'tile total':14s} mean {tot.mean():9.0f} cyc   median {np.median(tot):9.0f}   max {tot.max():9.0f}")
 print(ctx.last_counters())
