@@ -116,8 +116,10 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
-    const int tyrows = sb_thc_tile_rows(H);
-    const int tx = (g.nx + 63) / 64, ty = (g.rows + tyrows - 1) / tyrows;
+    const bool use_thc2 = H <= 16 && !getenv("SB_OLD_THC");
+    int txw, tyrows;
+    sb_thc_tile_shape(H, use_thc2, &txw, &tyrows);
+    const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
     // raises flags in this call's buffer, k_final clears the other one for the next call, so no
     // memset sits on the critical path and the last call's values stay readable.
@@ -132,6 +134,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     int *flags_now = (int *)c->tiles.p + (size_t)c->flag_parity * nflag;
     int *flags_next = (int *)c->tiles.p + (size_t)(1 - c->flag_parity) * nflag;
     job.thc_ty = tyrows; job.thc_ntx = tx; job.thc_nty = ty;
+    job.thc_txs = txw == 32 ? 5 : 6;
     job.bandbits = (uint64_t *)c->bandbits.p;
     job.clsbits = (uint64_t *)c->clsbits.p;
     job.stats = (const T *)c->stats;
@@ -147,7 +150,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     // the host-model flavour derives t0 inside k_thc; the f2py flavour returns the t0 plane
     job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
     // whole single-domain calls on the k_thc2 path: contrast first, k_wind applies the update
-    job.wind_final = (phases == 3 && !c->gathered && H <= 16 && !getenv("SB_OLD_THC")) ? 1 : 0;
+    job.wind_final = (phases == 3 && !c->gathered && use_thc2) ? 1 : 0;
     // one workspace field: t0 itself (f2py flavour) or gz = (gmma*z)*sigmoid(sigma) (host-model flavour)
     if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
     job.t0 = (T *)c->t0.p;

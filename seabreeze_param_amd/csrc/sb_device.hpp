@@ -42,6 +42,18 @@ __host__ __device__ inline Moments moments_merge(const Moments &a, const Moments
 }
 
 #ifdef __HIPCC__
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (gfx9
+// family): six VALU steps, where a shuffle-based scan pays six LDS-crossbar round trips.
+__device__ __forceinline__ int sb_wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 #define SB_STATS_NT 1024             // threads of every workgroup that merges moments
 
 __device__ __forceinline__ Moments wave_merge(Moments m) {
@@ -145,7 +157,8 @@ struct DiagJob {
     uint64_t *bandbits;             // nyh * nw words: interior cells with |mask| <= maxdist
     uint64_t *clsbits;              // nyh * nw words: mask >= 0 ("land side")
     const T *stats;                 // [0]=std  [1]=r  (sigmoid scalars)
-    int thc_ty, thc_ntx, thc_nty;   // k_thc tile rows and tile-grid shape (tiles are 64 x thc_ty cells)
+    int thc_ty, thc_ntx, thc_nty;   // contrast-kernel tile rows and tile-grid shape
+    int thc_txs;                    // log2 of the tile width (6: 64 longitudes, k_thc; 5: 32, k_thc2)
     int *tile_nnmax;                // per thc tile: 0 = no band cell; k_prep raises 1, k_thc leaves the largest radius
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
     long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock stamps per thc tile

@@ -218,13 +218,14 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 job.bandbits[seg] = wb;
             }
             if (wb) {                                            // wave-uniform
-                // the segment straddles two tile columns when the ghost width is not a multiple of 64
-                const int tA = ((int)(t.W[q] * 64u) - g.h) >> 6;
-                const uint64_t mB = __ballot(band && (xi >> 6) != tA);
-                if (lane == 0) {
-                    const int trow = (yi / job.thc_ty) * job.thc_ntx;
-                    if (wb & ~mB) job.tile_nnmax[trow + tA] = 1;     // plain stores of 1: benign duplicates
-                    if (mB) job.tile_nnmax[trow + tA + 1] = 1;
+                // the tile columns the segment's band cells fall in: two or three of them (one more when
+                // the ghost width is not a multiple of the tile width)
+                const int txs = job.thc_txs;
+                const int tA = ((int)(t.W[q] * 64u) - g.h) >> txs;
+                const int trow = (yi / job.thc_ty) * job.thc_ntx;
+                for (int j = 0; j <= (64 >> txs); ++j) {
+                    const uint64_t mj = __ballot(band && (xi >> txs) == tA + j);
+                    if (mj && lane == 0) job.tile_nnmax[trow + tA + j] = 1;    // plain stores of 1: benign duplicates
                 }
             }
             if (interior && yi < g.rows && !band) {
@@ -373,15 +374,30 @@ __device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ ban
 // level for all cells).
 // ------------------------------------------------------------------------------------
 template <typename T, int UN, bool NTL>
-__global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job) {
+__global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job, int ystride, int early) {
     __shared__ unsigned short s_x[ROW_NT];
     __shared__ int s_wcnt[ROW_NT / SB_WAVE];
     const Geo g = job.g;
-    const int y = blockIdx.y;
     // clear the other tile-flag buffer for the next call (this call's is read by k_thc)
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     for (int i = bid * ROW_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * gridDim.y * ROW_NT)
         job.next_flags[i] = 0;
+    // row of this workgroup: with ystride S, consecutive blockIdx.y are rows/S apart (experiment)
+    int y = blockIdx.y;
+    if (ystride > 1) {
+        const int per = (g.rows + ystride - 1) / ystride;
+        y = ((int)blockIdx.y % ystride) * per + (int)blockIdx.y / ystride;
+        if (y >= g.rows) return;
+    }
+    if (early) {
+        // no band cell among the 256 longitudes: leave before any LDS traffic or barrier.  Every wave
+        // looks at the same (at most five) words of the band plane, so the four waves agree.
+        const int X0 = blockIdx.x * ROW_NT + g.h, w0 = X0 >> 6;
+        const int lane = threadIdx.x & 63;
+        const int nwd = min(g.nw - w0, ROW_NT / 64 + ((X0 & 63) ? 1 : 0));
+        const uint64_t w = job.bandbits[(size_t)(y + g.h) * g.nw + w0 + (lane < nwd ? lane : 0)];
+        if (__ballot(lane < nwd && w != 0) == 0) return;
+    }
     const int total = block_band_cells(job.bandbits, g, y, s_x, s_wcnt);
     if ((int)threadIdx.x >= total) return;
     const int x = blockIdx.x * ROW_NT + s_x[threadIdx.x];
@@ -495,10 +511,13 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if ((e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
                                    (T *)lc.stats, st)) != hipSuccess) return e;
         if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[2], st); }
-        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
-        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
-        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
+        static const int ystr = getenv("SB_WIND_YSTRIDE") ? atoi(getenv("SB_WIND_YSTRIDE")) : 1;   // tuning knob (diagnostic)
+        static const int early = getenv("SB_WIND_EARLY") ? atoi(getenv("SB_WIND_EARLY")) : 0;       // tuning knob (diagnostic)
+        const int gy = ystr > 1 ? ystr * ((g.rows + ystr - 1) / ystr) : g.rows;
+        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, gy), wb(ROW_NT);
+        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
+        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, ystr, early);
+        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, ystr, early);
         if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[7], st); }
         return hipGetLastError();
     }
@@ -518,10 +537,10 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (ev) (void)hipEventRecord(ev[2], st);
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
         static const bool plain = getenv("SB_WIND_PLAIN") != nullptr;   // tuning knob (diagnostic)
-        if (plain) hipLaunchKernelGGL((k_wind<T, 8, false>), wg, wb, 0, st, job);
-        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job);
-        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job);
+        if (plain) hipLaunchKernelGGL((k_wind<T, 8, false>), wg, wb, 0, st, job, 1, 0);
+        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, 1, 0);
+        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, 1, 0);
+        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, 1, 0);
         if (ev) (void)hipEventRecord(ev[3], st);
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------

@@ -26,6 +26,10 @@
 
 #define THC_NT 1024
 #define THC_MAXMINE 256          // active tiles one workgroup can own
+// k_thc2 tiles are 32 longitudes x 64 latitudes: with the halo a staged row is exactly one 64-lane
+// chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
+#define THC2_TX 32
+#define THC2_TY 64
 #define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
 
 // ------------------------------------------------------------------------------------
@@ -86,101 +90,113 @@ __device__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, T sd,
 // round-robin to its workgroups: tiles staged at the same time on one XCD are neighbours,
 // and the halo cells they share are fetched from HBM once.
 // ------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void thc_list_preload(const int *__restrict__ flags, int ntiles, int (&v)[SB_WAVE / (NT / SB_WAVE)]) {
+    constexpr int K = SB_WAVE / (NT / SB_WAVE);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int t = k * NT + (int)threadIdx.x;
+        v[k] = flags[t < ntiles ? t : ntiles - 1];
+    }
+}
+
+// The position -> tile lookup of one chunk, by the first wave: lane e holds the count c and the inclusive
+// prefix incl of entry e (tile order: k major, then wave); s_bm holds the entries' ballots.
+template <int NT>
+__device__ __forceinline__ void thc_list_lookup(int ch, int base, int c, int incl, int nmine, bool xcd_map, int per,
+                                                int nper, const unsigned long long *s_bm, int *s_mine) {
+    constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;
+    const int lane = threadIdx.x & 63;
+    const int xq = (int)blockIdx.x % 8, local = (int)blockIdx.x / 8;
+    for (int j = 0; j < nmine; ++j) {
+        const int pos = xcd_map ? xq * per + local + j * nper : (int)blockIdx.x + j * (int)gridDim.x;
+        const int rel = pos - base;
+        const uint64_t hit = __ballot(lane < NE && rel >= incl - c && rel < incl);
+        if (hit) {                                           // wave-uniform: the position lies in this chunk
+            const int e = __ffsll((unsigned long long)hit) - 1;
+            int nth = rel - (__shfl(incl, e) - __shfl(c, e));   // which set bit of that entry's ballot
+            const uint64_t bm = s_bm[e];
+            int bit = 0;
+#pragma unroll
+            for (int w = 32; w > 0; w >>= 1) {               // select the nth set bit: halve the range six times
+                const int cnt = __popcll((bm >> bit) & ((1ull << w) - 1ull));
+                if (nth >= cnt) { nth -= cnt; bit += w; }
+            }
+            if (lane == 0) s_mine[j] = (ch * K + e / NWV) * NT + (e % NWV) * SB_WAVE + bit;
+        }
+    }
+}
+
+// The ordered list of active tiles this workgroup owns -> s_mine[0..n).  s_wcnt: 64 ints, s_bm: 64
+// ballot words.  A chunk is K * NT = 64 * 64 tiles whose flags are all loaded at once; `pre`: the flags of
+// chunk 0 already loaded by thc_list_preload (issued early, so that other work hides the round trip), or
+// nullptr.  A grid of at most one chunk (4096 tiles) needs two barriers and no second look at the flags.
 template <int NT = THC_NT>
 __device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int ntiles, int *s_mine, int *s_wcnt,
-                                              unsigned long long *s_mine2) {
-    // s_wcnt: 64 ints, s_mine2: 64 ballot words.  A chunk is K * NT = 64 * 64 tiles whose flags are
-    // all loaded at once (one global round trip per chunk and pass; a single-chunk grid keeps the
-    // flags of the counting pass in registers for the assignment pass).
+                                              unsigned long long *s_bm, const int *pre = nullptr) {
     constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;   // K flag loads in flight per thread
     static_assert(NE <= SB_WAVE, "the count table is prefixed by one wave");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nchunks = (ntiles + K * NT - 1) / (K * NT);
-    bool f[K];
-    // ---- pass A: number of active tiles ------------------------------------------------------
-    int total_active = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        int v[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {            // loads from clamped addresses, never under a branch:
-            const int t = (ch * K + k) * NT + tid;   // a conditional load is waited for inside its branch
-            v[k] = flags[t < ntiles ? t : ntiles - 1];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            f[k] = (ch * K + k) * NT + tid < ntiles && v[k] != 0;
-            const uint64_t bm = __ballot(f[k]);
-            if (lane == 0) s_wcnt[k * NWV + wv] = __popcll(bm);
-        }
-        __syncthreads();
-        int c = lane < NE ? s_wcnt[lane] : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-        total_active += c;
-        __syncthreads();
-    }
     const bool xcd_map = (gridDim.x % 8 == 0);
-    const int per = (total_active + 7) / 8, nper = (int)gridDim.x / 8;
-    // how many entries of the row-major list this workgroup owns, and which (position of entry j)
-    int nmine;
+    const int nper = (int)gridDim.x / 8;
     const int xq = (int)blockIdx.x % 8, local = (int)blockIdx.x / 8;
-    if (xcd_map) {
-        int cnt = total_active - xq * per;
-        cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
-        nmine = cnt > local ? (cnt - 1 - local) / nper + 1 : 0;
-    } else {
-        nmine = total_active > (int)blockIdx.x ? (total_active - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    }
-    nmine = nmine > THC_MAXMINE ? THC_MAXMINE : nmine;   // the launcher sizes the grid so this never binds
-    // ---- pass B: the tile at each of those positions.  Per chunk the ballots of every wave go to LDS;
-    // thread j then finds the (k, wave) entry whose range of positions holds its position and picks
-    // the matching set bit -- no per-tile division or modulo (integer division is a long instruction
-    // sequence, and the old form ran it for every active tile in every workgroup).
-    uint64_t *s_bm = (uint64_t *)s_mine2;                // NE ballot words, 8-byte aligned by the caller
-    int base = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (nchunks > 1) {
-            int v[K];
+    // ballots of one chunk -> LDS; returns after the barrier with (count, inclusive prefix) of entry `lane`
+    auto chunk = [&](int ch, bool use_pre, int &c, int &incl) {
+        int v[K];
+        if (use_pre) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int t = (ch * K + k) * NT + tid;
+            for (int k = 0; k < K; ++k) v[k] = pre[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {            // loads from clamped addresses, never under a branch:
+                const int t = (ch * K + k) * NT + tid;   // a conditional load is waited for inside its branch
                 v[k] = flags[t < ntiles ? t : ntiles - 1];
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) f[k] = (ch * K + k) * NT + tid < ntiles && v[k] != 0;
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint64_t bm = __ballot(f[k]);
+            const uint64_t bm = __ballot((ch * K + k) * NT + tid < ntiles && v[k] != 0);
             if (lane == 0) { s_wcnt[k * NWV + wv] = __popcll(bm); s_bm[k * NWV + wv] = bm; }
         }
         __syncthreads();
-        // inclusive prefix of the NE counts (tile order: k major, then wave)
-        const int c = lane < NE ? s_wcnt[lane] : 0;
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < SB_WAVE; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
+        c = lane < NE ? s_wcnt[lane] : 0;
+        incl = sb_wave_scan_add(c);
+    };
+    auto owned = [&](int total_active, int per) {
+        int n;
+        if (xcd_map) {
+            int cnt = total_active - xq * per;
+            cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
+            n = cnt > local ? (cnt - 1 - local) / nper + 1 : 0;
+        } else {
+            n = total_active > (int)blockIdx.x ? (total_active - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
         }
-        const int chunk_total = __shfl(incl, SB_WAVE - 1);
-        // wave 0: lane e knows the range [base + incl - c, base + incl) of entry e
-        if (wv == 0) {
-            for (int j = 0; j < nmine; ++j) {
-                const int pos = xcd_map ? xq * per + local + j * nper : (int)blockIdx.x + j * (int)gridDim.x;
-                const int rel = pos - base;
-                const uint64_t hit = __ballot(lane < NE && rel >= incl - c && rel < incl);
-                if (hit) {                                       // wave-uniform: the position lies in this chunk
-                    const int e = __ffsll((unsigned long long)hit) - 1;
-                    const int nth = rel - (__shfl(incl, e) - __shfl(c, e));   // which set bit of that ballot
-                    uint64_t bm = s_bm[e];
-                    for (int i = 0; i < nth; ++i) bm &= bm - 1;   // drop the nth lowest set bits (nth < 64)
-                    const int bit = __ffsll((unsigned long long)bm) - 1;
-                    if (lane == 0) s_mine[j] = (ch * K + e / NWV) * NT + (e % NWV) * SB_WAVE + bit;
-                }
-            }
-        }
-        base += chunk_total;
+        return n > THC_MAXMINE ? THC_MAXMINE : n;        // the launcher sizes the grid so this never binds
+    };
+    int c, incl;
+    if (nchunks == 1) {
+        chunk(0, pre != nullptr, c, incl);
+        const int total_active = __shfl(incl, SB_WAVE - 1);
+        const int per = (total_active + 7) / 8;
+        const int nmine = owned(total_active, per);
+        if (wv == 0) thc_list_lookup<NT>(0, 0, c, incl, nmine, xcd_map, per, nper, s_bm, s_mine);
+        __syncthreads();
+        return nmine;
+    }
+    int total_active = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        chunk(ch, ch == 0 && pre != nullptr, c, incl);
+        total_active += __shfl(incl, SB_WAVE - 1);
+        __syncthreads();
+    }
+    const int per = (total_active + 7) / 8;
+    const int nmine = owned(total_active, per);
+    int base = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        chunk(ch, false, c, incl);
+        if (wv == 0) thc_list_lookup<NT>(ch, base, c, incl, nmine, xcd_map, per, nper, s_bm, s_mine);
+        base += __shfl(incl, SB_WAVE - 1);
         __syncthreads();
     }
     return nmine;
@@ -516,9 +532,9 @@ struct ThcRegs {
     T c0;                          // the tile's offset
 };
 
-template <typename T, int TY, int H, bool FLY, int RPW, int NCH>
+template <typename T, int TX, int TY, int H, bool FLY, int RPW, int NCH>
 __device__ __forceinline__ void thc2_issue(const DiagJob<T> &job, int tile, ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
-    constexpr int TX = 64, W = TX + 2 * H;
+    constexpr int W = TX + 2 * H;
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ntx = job.thc_ntx;
@@ -609,10 +625,10 @@ __device__ __forceinline__ void thc2_issue_late(const DiagJob<T> &job, int tile,
     }
 }
 
-template <typename T, int TY, int H, bool FLY>
+template <typename T, int TX, int TY, int H, bool FLY>
 __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments *__restrict__ partials, int nparts,
                                                   T *__restrict__ stats_out) {
-    constexpr int TX = 64, NT = THC2_NT, NWV = NT / SB_WAVE;
+    constexpr int NT = THC2_NT, NWV = NT / SB_WAVE;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
     constexpr int RPW = HT / NWV;                // consecutive table rows a wave owns
     constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
     constexpr int CPT = (TX * TY + NT - 1) / NT; // list entries per thread in the search
     static_assert(HT % NWV == 0, "every wave owns the same number of rows");
     static_assert(W % NSEG == 0 && (2 * HT * NSEG) % SB_WAVE == 0, "row-pass task shape");
-    static_assert(TY <= SB_WAVE && TY <= NT && NC <= 32, "tile shape");
+    static_assert(TX <= SB_WAVE && TY <= SB_WAVE && TY <= NT && NC <= 32, "tile shape");
     static_assert((size_t)W * HT < 65536, "u16 count table");
     __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
     __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
@@ -663,19 +679,12 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
             }
         }
     }
+    int preflags[SB_WAVE / NWV];
+    thc_list_preload<NT>(job.tile_nnmax, ntiles, preflags);
     SB_PSTAMP(0);
-    const int nmine = thc_build_list<NT>(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw);
-#ifdef SB_STAMPS
-    const long long t_list = clock64();
-#endif
-    ThcRegs<T, NC, NCH, FLY> R;
-    if (nmine > 0) thc2_issue<T, TY, H, FLY, RPW, NCH>(job, s_mine[0], R);
-    SB_PSTAMP(1);
-    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
-    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
     // sigmoid scalars: merged here from k_scan's per-workgroup moments, in the fixed order and
-    // tree of k_moments_final, so every workgroup (and that kernel) gets the same bits
-    SB_PSTAMP(2);
+    // tree of k_moments_final, so every workgroup (and that kernel) gets the same bits.  The merge
+    // runs while the tile flags are still on their way.
     T sd = T(0), rr = T(0);
     if constexpr (FLY) {
         if (nparts > 0) {
@@ -703,8 +712,21 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
                 sigmoid_scalars<T>(m, s_stats);
                 if (blockIdx.x == 0 && stats_out) sigmoid_scalars<T>(m, stats_out);
             }
-            __syncthreads();
-            sd = s_stats[0];
+        }
+    }
+    const int nmine = thc_build_list<NT>(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw, preflags);   // has barriers
+#ifdef SB_STAMPS
+    const long long t_list = clock64();
+#endif
+    ThcRegs<T, NC, NCH, FLY> R;
+    if (nmine > 0) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, s_mine[0], R);
+    SB_PSTAMP(1);
+    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
+    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+    SB_PSTAMP(2);
+    if constexpr (FLY) {
+        if (nparts > 0) {
+            sd = s_stats[0];                   // written before the list's barriers
             rr = s_stats[1];
         } else {
             sd = job.stats[0];
@@ -735,6 +757,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
                 const int sh = R.bsh & 63;
                 w = R.bw0 >> sh;
                 if (sh && R.bsh < 64) w |= R.bw1 << (64 - sh);
+                if (TX < 64) w &= (1ull << (TX & 63)) - 1ull;
             }
             s_word[tid] = w;
         }
@@ -746,20 +769,25 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
         SB_STAMP(26);
         int total;
         {
+            // every wave prefixes the TY popcounts for itself; then lane (r, j) of a wave walks byte j of
+            // the band word of one of the wave's rows -- at most 8 list entries per lane
             const int pc = lane < TY ? __popcll(s_word[lane]) : 0;
-            int incl = pc;
-#pragma unroll
-            for (int d = 1; d < SB_WAVE; d <<= 1) {
-                const int t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
-            }
+            const int incl = sb_wave_scan_add(pc);
             total = __shfl(incl, SB_WAVE - 1);
             const int excl = incl - pc;
-            for (int r = wv; r < TY; r += NWV) {
-                const uint64_t w = s_word[r];
-                const int off = __shfl(excl, r);
-                if ((w >> lane) & 1ull)
-                    s_cell[off + __popcll(w & ((1ull << lane) - 1ull))] = (unsigned short)((r << 6) | lane);
+            constexpr int NB = TX / 8;                           // bytes of a band word that belong to the tile
+            constexpr int RPI = SB_WAVE / NB;                    // rows a wave covers per iteration
+            for (int rb = wv * RPI; rb < TY; rb += NWV * RPI) {
+                const int r = rb + lane / NB, j = lane % NB;
+                const bool have = r < TY;
+                const uint64_t w = s_word[have ? r : 0];
+                int pos = __shfl(excl, have ? r : 0) + __popcll(w & ((1ull << (8 * j)) - 1ull));
+                unsigned bits = have ? (unsigned)((w >> (8 * j)) & 0xffull) : 0u;
+                while (bits) {
+                    const int b = __ffs(bits) - 1;
+                    s_cell[pos++] = (unsigned short)((r << 6) | (8 * j + b));
+                    bits &= bits - 1;
+                }
             }
         }
         lds_barrier();
@@ -831,7 +859,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
         }
         asm volatile("" : "+v"(ownbits));        // materialise here: the compiler would sink this into T4
         // the next tile's loads fly under T2..T4 (and under the other workgroups' staging)
-        if (mi + 1 < nmine) thc2_issue<T, TY, H, FLY, RPW, NCH>(job, s_mine[mi + 1], R);
+        if (mi + 1 < nmine) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, s_mine[mi + 1], R);
         lds_barrier();
         SB_STAMP(2);
         // ---- T2: exclusive prefix of the band totals along latitude ------------------------------
@@ -860,19 +888,38 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
         // ---- T3: prefix along longitude (+ band offsets); count table: band offsets only ---------
         // 16 consecutive lanes take 16 consecutive rows of one run (the pitch is odd, so their 8-byte
         // elements fall in 16 different bank pairs); the four 16-lane groups of a wave and the two
-        // tasks of a thread cover the 8 runs of those rows, in an order that also keeps the two
-        // groups of a 32-lane read apart (runs 0,4 | 1,5 and 2,6 | 3,7 for 12-cell runs)
+        // tasks of a thread cover the 8 runs of those rows.  The two groups of a 32-lane read are given
+        // runs whose starts are 16 elements apart modulo 32 (4 runs apart for 12-cell runs, 2 for
+        // 8-cell runs), so that they do not share banks either.
         {
             static_assert((2 * HT) % 16 == 0 && NSEG == 8, "row-pass lane mapping");
             constexpr int NRG = 2 * HT / 16;         // 16-row groups over both fp64 tables
+            constexpr int NRND = (NRG + NWV - 1) / NWV, SPARE = NRND * NWV - NRG;   // idle wave slots of the last round
+            constexpr int DSEG = (SEG % 8 == 4) ? 4 : (SEG % 16 == 8) ? 2 : 1;
+            constexpr int CT = HT * NSEG;            // count-table tasks (one run each)
             const int grp = lane >> 4;
-            for (int rg = wv; rg < NRG; rg += NWV) {
+            // runs of group q: first task, second task
+            auto run0 = [](int q) { return DSEG == 4 ? (q >> 1) + ((q & 1) << 2) : DSEG == 2 ? (q >> 1) + ((q & 1) << 1) : q; };
+            auto run1 = [&](int q) { return run0(q) + (DSEG == 4 ? 2 : 4); };
+            auto count_tasks = [&](int first, int step) {
+                for (int task = first; task < CT; task += step) {
+                    const int row = (task & 15) + 16 * (task / (16 * NSEG)), seg = (task >> 4) & (NSEG - 1);
+                    unsigned short *tab = sC + (row + 1) * P + 1 + seg * SEG;
+                    const int *off = pC + (row / RPW) * W + seg * SEG;
+#pragma unroll
+                    for (int i = 0; i < SEG; ++i) tab[i] = (unsigned short)((int)tab[i] + off[i]);
+                }
+            };
+            for (int rg = wv; rg < NRND * NWV; rg += NWV) {
+                if (rg >= NRG) {                                 // wave-uniform: a spare slot takes count-table tasks
+                    if (SPARE > 0) count_tasks((rg - NRG) * SB_WAVE + lane, SPARE * SB_WAVE);
+                    continue;
+                }
                 const int trow = rg * 16 + (lane & 15);          // row over both tables
                 const int a = trow / HT, row = trow - a * HT;
                 double *trw = (a == 0 ? sA : sL) + (row + 1) * P + 1;
                 const double *orw = (a == 0 ? pA : pL) + (row / RPW) * W;
-                const int sg0 = (grp >> 1) + ((grp & 1) << 2);   // 0,4,1,5
-                const int sg1 = sg0 + 2;                         // 2,6,3,7
+                const int sg0 = run0(grp), sg1 = run1(grp);
                 double v0[SEG], v1[SEG], s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int i = 0; i < SEG; ++i) {
@@ -885,10 +932,9 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
                 double tot[NSEG];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int src = (lane & 15) + 16 * q;        // group q holds runs (q>>1)+4*(q&1) and that + 2
-                    const int r0 = (q >> 1) + ((q & 1) << 2);
-                    tot[r0] = __shfl(s0, src);
-                    tot[r0 + 2] = __shfl(s1, src);
+                    const int src = (lane & 15) + 16 * q;
+                    tot[run0(q)] = __shfl(s0, src);
+                    tot[run1(q)] = __shfl(s1, src);
                 }
                 double e0 = 0.0, e1 = 0.0, acc = 0.0;
 #pragma unroll
@@ -903,13 +949,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
                     trw[sg1 * SEG + i] = v1[i] + e1;
                 }
             }
-            for (int task = tid; task < HT * NSEG; task += NT) {
-                const int row = (task & 15) + 16 * (task / (16 * NSEG)), seg = (task >> 4) & (NSEG - 1);
-                unsigned short *tab = sC + (row + 1) * P + 1 + seg * SEG;
-                const int *off = pC + (row / RPW) * W + seg * SEG;
-#pragma unroll
-                for (int i = 0; i < SEG; ++i) tab[i] = (unsigned short)((int)tab[i] + off[i]);
-            }
+            if (SPARE == 0) count_tasks(tid, NT);
         }
         lds_barrier();
         SB_STAMP(4);
@@ -921,6 +961,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
             const bool valid = cq[q] >= 0;
+            if (__ballot(valid) == 0) continue;                  // wave-uniform: no lane of this wave has a q-th cell
             const int cc = valid ? cq[q] : 0;
             const int lx = cc & 63, ly = cc >> 6;
             const int x = x0 + lx, y = y0 + ly;
@@ -1003,13 +1044,13 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
 #endif
 }
 
-template <typename T, int TY, int H>
+template <typename T, int TX, int TY, int H>
 static void launch_thc2(const DiagJob<T> &job, int nblocks, const Moments *partials, int nparts, T *stats_out,
                         hipStream_t st) {
     if (job.t0_fly)
-        hipLaunchKernelGGL((k_thc2<T, TY, H, true>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
+        hipLaunchKernelGGL((k_thc2<T, TX, TY, H, true>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
     else
-        hipLaunchKernelGGL((k_thc2<T, TY, H, false>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
+        hipLaunchKernelGGL((k_thc2<T, TX, TY, H, false>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
 }
 
 template <typename T>
@@ -1018,8 +1059,8 @@ hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *
     const int ntiles = job.thc_ntx * job.thc_nty;
     int nblocks = ncu;
     while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
-    if (H <= 8) launch_thc2<T, 32, 8>(job, nblocks, partials, nparts, stats_out, st);
-    else launch_thc2<T, 32, 16>(job, nblocks, partials, nparts, stats_out, st);
+    if (H <= 8) launch_thc2<T, THC2_TX, THC2_TY, 8>(job, nblocks, partials, nparts, stats_out, st);
+    else launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
     return hipGetLastError();
 }
 template hipError_t sb_launch_thc2<float>(const DiagJob<float> &, int, int, const Moments *, int, float *, hipStream_t);
@@ -1033,6 +1074,10 @@ static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_
 }
 
 int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }
+void sb_thc_tile_shape(int H, bool thc2, int *tx, int *ty) {
+    if (thc2 && H <= 16) { *tx = THC2_TX; *ty = THC2_TY; }
+    else { *tx = 64; *ty = sb_thc_tile_rows(H); }
+}
 
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse, hipStream_t st) {
