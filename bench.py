@@ -39,10 +39,10 @@ def algorithmic_bytes(n, n_band, nz, s=8):
     """B = s*[5N + (nz+7)*N_c], split per kernel."""
     return {
         "k_scan": s * (3 * n - n_band),                    # read sigma, mask; write sb_con outside the band
-        "k_wind": s * (nz + 2) * n_band,                   # p column, u, v at band cells
-        "k_gz": 0,                                         # workspace only
-        "k_final": 0,                                      # its bytes are counted under k_thc
-        "k_thc": s * (2 * n + 6 * n_band),                 # theta, z in; thc out; ws, wd in; sb_con, ws, wd out
+        "k_thc": s * 2 * n,                                # k_thc2: theta, z in (sigma is read a second time: not counted)
+        "k_wind": s * (nz + 8) * n_band,                   # p column, u, v, ws, wd in; ws, wd, thc, sb_con out (band cells)
+        "k_gz": 0,                                         # not launched on the default path
+        "k_final": 0,
         "total": s * (5 * n + (nz + 7) * n_band),
     }
 

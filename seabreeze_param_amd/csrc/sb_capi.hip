@@ -639,7 +639,7 @@ int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
     HIPCHK(c, hipDeviceSynchronize());
-    // event pairs bracket k_scan (+ moments merge), k_wind, k_t0/k_gz, k_thc, join + k_final_tiles
+    // event pairs bracket k_scan (+ moments merge when it is a launch), k_wind, k_t0/k_gz, k_thc2/k_thc, (unused)
     static const int first[SB_PROF_KERNELS] = {0, 2, 4, 5, 6}, last[SB_PROF_KERNELS] = {1, 3, 5, 6, 7};
     double sum[SB_PROF_KERNELS] = {0, 0, 0, 0, 0};
     for (int i = 0; i < c->prof_calls; ++i)

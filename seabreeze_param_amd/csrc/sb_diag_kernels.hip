@@ -510,7 +510,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (ev) { (void)hipEventRecord(ev[5], st); }
         if ((e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
                                    (T *)lc.stats, st)) != hipSuccess) return e;
-        if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[2], st); }
+        if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[7], st); (void)hipEventRecord(ev[2], st); }
         static const int ystr = getenv("SB_WIND_YSTRIDE") ? atoi(getenv("SB_WIND_YSTRIDE")) : 1;   // tuning knob (diagnostic)
         static const int early = getenv("SB_WIND_EARLY") ? atoi(getenv("SB_WIND_EARLY")) : 0;       // tuning knob (diagnostic)
         const int gy = ystr > 1 ? ystr * ((g.rows + ystr - 1) / ystr) : g.rows;
@@ -518,7 +518,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
         else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, ystr, early);
         else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, ystr, early);
-        if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[7], st); }
+        if (ev) { (void)hipEventRecord(ev[3], st); }
         return hipGetLastError();
     }
     // ---- phase 1: needs neither theta's ghost cells nor the statistics -----------------------

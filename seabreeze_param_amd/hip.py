@@ -106,8 +106,9 @@ class Context:
 
     def profile_end(self):
         """-> ({'k_scan', 'k_wind', 'k_gz', 'k_thc', 'k_final'} -> ms, ncalls): HIP-event averages of the
-        launches of one diag call (k_scan includes the small moments merge; k_gz is k_t0 for the f2py
-        flavour; k_final is the join with k_wind + k_final_tiles, present only in overlap mode)."""
+        launches of one diag call.  k_thc is k_thc2 (moments merge, t0, tables, search) on the default
+        path; k_gz is k_t0 for the f2py flavour and empty for the host-model flavour (k_thc2 forms t0
+        itself); k_scan includes k_moments_final where that is still a launch; k_final is unused."""
         ms = (C.c_double * 5)()
         n = C.c_int(0)
         self._chk(self.lib.sb_profile_end(self.h, ms, C.byref(n)), "sb_profile_end")
