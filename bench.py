@@ -60,7 +60,8 @@ def pmc_traffic(kernel, nx, ny, nz):
     c = d.get("config", {})
     if (c.get("nx"), c.get("ny"), c.get("nz")) != (nx, ny, nz):
         return None
-    return d.get("kernels", {}).get(kernel, {}).get("hbm_bytes")
+    ks = d.get("kernels", {})
+    return (ks.get(kernel) or ks.get(kernel + "2") or {}).get("hbm_bytes")      # k_thc is k_thc2 on the default path
 
 
 def host_cores() -> int:

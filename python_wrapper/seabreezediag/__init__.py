@@ -42,8 +42,26 @@ def _pop(kwargs, key, default=None):
     return kwargs.pop(key) if key in kwargs else default
 
 
+_dist_cache = {"key": None, "dist": None}
+
+
 def _coast_distance(lsm, ice, lon, lat):
-    return c2f(get_dist(get_edges(c2f(lsm), c2f(ice)), c2f(lsm), lon, lat))
+    """Signed coast distance for this land mask and sea-ice field.  The reference recomputes it at
+    every timestep (ref :223-228); the result depends only on these four inputs, so the last one is
+    kept and reused while their bytes are unchanged -- sea ice in reanalysis
+    files changes daily, not with every model step."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=16)
+    for a in (lsm, ice, lon, lat):
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.view(np.uint8).reshape(-1).data)
+    key = h.digest()
+    if _dist_cache["key"] != key:
+        _dist_cache["dist"] = c2f(get_dist(get_edges(c2f(lsm), c2f(ice)), c2f(lsm), lon, lat))
+        _dist_cache["key"] = key
+    return _dist_cache["dist"]
 
 
 def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):

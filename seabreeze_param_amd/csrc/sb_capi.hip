@@ -358,10 +358,24 @@ int diag_host(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T 
     if (rc) return rc;
     if (!p || !z || !std_ || !theta || !v || !u || !cdist || !ws || !wd || !thc || !output)
         return fail(c, SB_ERR_ARG, "null array pointer");
-    const size_t n2 = (size_t)nlons * nlats, n3 = n2 * nps;
+    const size_t n2 = (size_t)nlons * nlats;
+    // p is one column for the whole grid (ref: seabreeze_diag_python.f90:228), so the level is known
+    // before anything is uploaded: pick it here exactly as the kernel would (first minimum, working
+    // precision, target converted like ref :148) and send only that u/v plane -- 2 planes instead of
+    // 2*nps over PCIe, same result.
+    int lev = 0;
+    {
+        const T tp = target_plev * T(100.);
+        T best = std::fabs(p[0] - tp);
+        for (int k = 1; k < nps; ++k) {
+            const T a = std::fabs(p[k] - tp);
+            if (a < best) { best = a; lev = k; }
+        }
+    }
     Stager s(c);
-    T *dp = s.in(p, (size_t)nps), *dz = s.in(z, n2), *dsd = s.in(std_, n2), *dth = s.in(theta, n2);
-    T *dv = s.in(v, n3), *du = s.in(u, n3), *dcd = s.in(cdist, n2);
+    T *dp = s.in(p + lev, (size_t)1), *dz = s.in(z, n2), *dsd = s.in(std_, n2), *dth = s.in(theta, n2);
+    T *dv = s.in(v + (size_t)lev * n2, n2), *du = s.in(u + (size_t)lev * n2, n2), *dcd = s.in(cdist, n2);
+    nps = 1;
     T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2);
     T *dout = s.in(output, 4 * n2);          // row nlats is left as the caller passed it
     if (s.rc) return s.rc;

@@ -344,24 +344,38 @@ __device__ __forceinline__ T sb_ld(const T *p) {
     else return *p;
 }
 
+template <int CPW>
 __device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ bandbits, const Geo &g, int y,
                                                 unsigned short *s_x, int *s_wcnt) {
+    // the workgroup covers CPW * ROW_NT consecutive longitudes: CPW chunks of ROW_NT, a wave on 64 of them
+    constexpr int NW = ROW_NT / SB_WAVE;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x = blockIdx.x * ROW_NT + tid;
-    bool band = false;
-    if (x < g.nx) band = sb_bit(bandbits, g.nw, x + g.h, y + g.h) != 0;
-    const uint64_t bm = __ballot(band);
-    if (lane == 0) s_wcnt[wv] = __popcll(bm);
-    __syncthreads();
-    int before = 0, total = 0;
+    bool band[CPW];
+    uint64_t bm[CPW];
 #pragma unroll
-    for (int w = 0; w < ROW_NT / SB_WAVE; ++w) {
-        const int cw = s_wcnt[w];
-        before += (w < wv) ? cw : 0;
-        total += cw;
+    for (int c = 0; c < CPW; ++c) {
+        const int x = (blockIdx.x * CPW + c) * ROW_NT + tid;
+        band[c] = x < g.nx && sb_bit(bandbits, g.nw, (x < g.nx ? x : 0) + g.h, y + g.h) != 0;
+        bm[c] = __ballot(band[c]);
+        if (lane == 0) s_wcnt[c * NW + wv] = __popcll(bm[c]);
+    }
+    __syncthreads();
+    int total = 0, before[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        before[c] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int cw = s_wcnt[c * NW + w];
+            before[c] += total * (w == 0 ? 1 : 0);               // entries of the chunks before this one
+            before[c] += (w < wv) ? cw : 0;
+            total += cw;
+        }
     }
     if (total == 0) return 0;
-    if (band) s_x[before + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+        if (band[c]) s_x[before[c] + __popcll(bm[c] & ((1ull << lane) - 1ull))] = (unsigned short)(c * ROW_NT + tid);
     __syncthreads();
     return total;
 }
@@ -371,12 +385,14 @@ __device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ ban
 // Band cells walk their p column (nz planes, stride nx*ny) with UN independent
 // non-temporal loads in flight and keep the first minimum of |p - target|
 // ref: generic/sea_breeze_diag.f90:223-227, seabreeze_diag_python.f90:228-233 (1-D p: one
-// level for all cells).
+// level for all cells).  A workgroup covers CPW * 256 longitudes of one row: most row blocks hold
+// no band cell, and the launch of their waves is a measurable share of the kernel (14 us for the
+// empty grid at CPW = 1 on the 2560 x 1920 grid), so fewer, wider workgroups are launched.
 // ------------------------------------------------------------------------------------
-template <typename T, int UN, bool NTL>
+template <typename T, int UN, bool NTL, int CPW = 1>
 __global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job, int ystride, int early) {
-    __shared__ unsigned short s_x[ROW_NT];
-    __shared__ int s_wcnt[ROW_NT / SB_WAVE];
+    __shared__ unsigned short s_x[ROW_NT * CPW];
+    __shared__ int s_wcnt[ROW_NT / SB_WAVE * CPW];
     const Geo g = job.g;
     // clear the other tile-flag buffer for the next call (this call's is read by k_thc)
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -389,64 +405,66 @@ __global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job, int ystride, in
         y = ((int)blockIdx.y % ystride) * per + (int)blockIdx.y / ystride;
         if (y >= g.rows) return;
     }
-    if (early) {
-        // no band cell among the 256 longitudes: leave before any LDS traffic or barrier.  Every wave
-        // looks at the same (at most five) words of the band plane, so the four waves agree.
-        const int X0 = blockIdx.x * ROW_NT + g.h, w0 = X0 >> 6;
+    if (early == 1) {
+        // no band cell among the longitudes: leave before any LDS traffic or barrier.  Every wave
+        // looks at the same words of the band plane, so the four waves agree.
+        const int X0 = blockIdx.x * ROW_NT * CPW + g.h, w0 = X0 >> 6;
         const int lane = threadIdx.x & 63;
-        const int nwd = min(g.nw - w0, ROW_NT / 64 + ((X0 & 63) ? 1 : 0));
+        const int nwd = min(g.nw - w0, ROW_NT * CPW / 64 + ((X0 & 63) ? 1 : 0));
         const uint64_t w = job.bandbits[(size_t)(y + g.h) * g.nw + w0 + (lane < nwd ? lane : 0)];
         if (__ballot(lane < nwd && w != 0) == 0) return;
     }
-    const int total = block_band_cells(job.bandbits, g, y, s_x, s_wcnt);
-    if ((int)threadIdx.x >= total) return;
-    const int x = blockIdx.x * ROW_NT + s_x[threadIdx.x];
+    const int total = block_band_cells<CPW>(job.bandbits, g, y, s_x, s_wcnt);
+    if (early == 2) return;                                      // diagnostic: cost of the empty grid
     const size_t pl = (size_t)g.nx * g.ny;
-    const size_t o = (size_t)y * g.nx + x;
     const int nz = job.nz;
-    // the final update's inputs: issued ahead of the column walk
-    T n_thc = T(0), ws_old = T(0), wd_old = T(0);
-    if (job.wind_final) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
-    int lev = 0;
-    if (job.flavour == SB_FLAVOUR_GENERIC) {
-        // whole batches of UN levels in flight; the last batch is padded by re-reading level
-        // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
-        // loads follows the batches
-        const T *pc = job.p + o;
-        T best = T(0);
-        for (int k0 = 0; k0 < nz; k0 += UN) {
-            T d[UN];
+    for (int i = threadIdx.x; i < total; i += ROW_NT) {
+        const int x = blockIdx.x * ROW_NT * CPW + s_x[i];
+        const size_t o = (size_t)y * g.nx + x;
+        // the final update's inputs: issued ahead of the column walk
+        T n_thc = T(0), ws_old = T(0), wd_old = T(0);
+        if (job.wind_final) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
+        int lev = 0;
+        if (job.flavour == SB_FLAVOUR_GENERIC) {
+            // whole batches of UN levels in flight; the last batch is padded by re-reading level
+            // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
+            // loads follows the batches
+            const T *pc = job.p + o;
+            T best = T(0);
+            for (int k0 = 0; k0 < nz; k0 += UN) {
+                T d[UN];
 #pragma unroll
-            for (int q = 0; q < UN; ++q) {
-                const int k = k0 + q < nz ? k0 + q : nz - 1;
-                d[q] = sb_ld<T, NTL>(pc + (size_t)k * pl);
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q < nz ? k0 + q : nz - 1;
+                    d[q] = sb_ld<T, NTL>(pc + (size_t)k * pl);
+                }
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q;
+                    const T a = fabs(d[q] - job.target_plev);
+                    if (k == 0) best = a;                        // the search starts at level 1 (ref :223)
+                    else if (k < nz && a < best) { best = a; lev = k; }
+                }
             }
-#pragma unroll
-            for (int q = 0; q < UN; ++q) {
-                const int k = k0 + q;
-                const T a = fabs(d[q] - job.target_plev);
-                if (k == 0) best = a;                            // the search starts at level 1 (ref :223)
-                else if (k < nz && a < best) { best = a; lev = k; }
+        } else {
+            T best = fabs(job.p[0] - job.target_plev);
+            for (int k = 1; k < nz; ++k) {
+                const T a = fabs(job.p[k] - job.target_plev);
+                if (a < best) { best = a; lev = k; }
             }
         }
-    } else {
-        T best = fabs(job.p[0] - job.target_plev);
-        for (int k = 1; k < nz; ++k) {
-            const T a = fabs(job.p[k] - job.target_plev);
-            if (a < best) { best = a; lev = k; }
+        const T uu = job.u[(size_t)lev * pl + o];
+        const T vv = job.v[(size_t)lev * pl + o];
+        const T n_ws = sqrt(uu * uu + vv * vv);                  // ref :225
+        const T n_wd = atan2(-uu, -vv) * T(57.2957);             // ref :227, rad2deg (sic) :128
+        if (job.wind_final) {
+            // k_thc2 ran first and left this call's contrast in thc: thresholds, scaling and state
+            // update happen here, under the HBM latency of the column walk   ref :235-266
+            sb_trigger_update<T>(job, o, n_thc, SbCellState<T>{n_ws, n_wd, ws_old, wd_old});
+        } else {
+            job.nws[o] = n_ws;
+            job.nwd[o] = n_wd;
         }
-    }
-    const T uu = job.u[(size_t)lev * pl + o];
-    const T vv = job.v[(size_t)lev * pl + o];
-    const T n_ws = sqrt(uu * uu + vv * vv);                      // ref :225
-    const T n_wd = atan2(-uu, -vv) * T(57.2957);                 // ref :227, rad2deg (sic) :128
-    if (job.wind_final) {
-        // k_thc2 ran first and left this call's contrast in thc: thresholds, scaling and state
-        // update happen here, under the HBM latency of the column walk   ref :235-266
-        sb_trigger_update<T>(job, o, n_thc, SbCellState<T>{n_ws, n_wd, ws_old, wd_old});
-    } else {
-        job.nws[o] = n_ws;
-        job.nwd[o] = n_wd;
     }
 }
 
@@ -513,9 +531,12 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[7], st); (void)hipEventRecord(ev[2], st); }
         static const int ystr = getenv("SB_WIND_YSTRIDE") ? atoi(getenv("SB_WIND_YSTRIDE")) : 1;   // tuning knob (diagnostic)
         static const int early = getenv("SB_WIND_EARLY") ? atoi(getenv("SB_WIND_EARLY")) : 0;       // tuning knob (diagnostic)
+        static const int cpw = getenv("SB_WIND_CPW") ? atoi(getenv("SB_WIND_CPW")) : 1;           // tuning knob (diagnostic)
         const int gy = ystr > 1 ? ystr * ((g.rows + ystr - 1) / ystr) : g.rows;
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, gy), wb(ROW_NT);
-        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
+        if (cpw == 2) hipLaunchKernelGGL((k_wind<T, 8, true, 2>), dim3((g.nx + 2 * ROW_NT - 1) / (2 * ROW_NT), gy), wb, 0, st, job, ystr, early);
+        else if (cpw == 4) hipLaunchKernelGGL((k_wind<T, 8, true, 4>), dim3((g.nx + 4 * ROW_NT - 1) / (4 * ROW_NT), gy), wb, 0, st, job, ystr, early);
+        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
         else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, ystr, early);
         else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, ystr, early);
         if (ev) { (void)hipEventRecord(ev[3], st); }

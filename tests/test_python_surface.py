@@ -84,3 +84,44 @@ def test_python_surface_matches_reference_golden():
         assert np.array_equal(m > 1e19, fill)
         d = np.abs(m - r)[~fill]
         assert np.quantile(d, 0.995) < 5e-3, np.quantile(d, 0.995)   # knife-edge cells may flip at fp32
+
+
+@pytest.mark.skipif(not _built(), reason="python_wrapper extension not built")
+def test_coast_distance_is_reused_while_its_inputs_are_unchanged(monkeypatch):
+    """The driver recomputes get_edges + get_dist only when lsm / ci / lon / lat change (the reference
+    recomputes them every step, ref: python_wrapper/seabreezediag/__init__.py:223-228, with the same
+    result).  Host logic only: the three extension routines are replaced by counting stand-ins."""
+    _, sbd = _import_surface()
+    calls = {"edges": 0, "dist": 0, "diag": 0}
+
+    def fake_edges(lsm, ci):
+        calls["edges"] += 1
+        return np.asfortranarray(np.zeros(lsm.shape, np.float32))
+
+    def fake_dist(coast, mask, lon, lat):
+        calls["dist"] += 1
+        return np.asfortranarray(np.full(coast.shape, float(calls["dist"]), np.float32))
+
+    def fake_diag(tt, p, z, std, t, v, u, dist, ws, wd, thc, **kw):
+        calls["diag"] += 1
+        out = np.zeros(z.shape + (4,), np.float32, order="F")
+        out[..., 0] = dist          # lets the test see which distance field a step used
+        return out
+
+    monkeypatch.setattr(sbd, "get_edges", fake_edges)
+    monkeypatch.setattr(sbd, "get_dist", fake_dist)
+    monkeypatch.setattr(sbd, "_diag_kernel", fake_diag)
+    monkeypatch.setitem(sbd._dist_cache, "key", None)
+    nt, nlev, nlat, nlon = 4, 3, 6, 8
+    lsm = np.zeros((nlat, nlon), np.float32)
+    z = std = lsm
+    lon, lat = np.arange(nlon, dtype=np.float32), np.arange(nlat, dtype=np.float32)
+    pres = np.array([1000., 700., 500.], np.float32)
+    u = v = np.zeros((nt, nlev, nlat, nlon), np.float32)
+    t = np.zeros((nt, nlat, nlon), np.float32)
+    ci = np.zeros((nt, nlat, nlon), np.float32)
+    ci[2:] = 0.5                                     # the ice field changes once, before step 3
+    tt, sb, *_ = sbd.diag(1, lsm, z, std, lon, lat, pres, u, v, t, ci)
+    assert tt == 1 + nt and calls["diag"] == nt
+    assert calls["edges"] == 2 and calls["dist"] == 2            # not 4 and 4
+    assert [float(sb[i].max()) for i in range(nt)] == [1.0, 1.0, 2.0, 2.0]
