@@ -35,12 +35,13 @@ from seabreeze_param_amd.bands import BandRunner, split_rows  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(n, n_band, nz, s=8):
+def algorithmic_bytes(n, n_band, nz, s=8, wind_final=True):
     """B = s*[5N + (nz+7)*N_c], split per kernel."""
     return {
         "k_scan": s * (3 * n - n_band),                    # read sigma, mask; write sb_con outside the band
-        "k_thc": s * 2 * n,                                # k_thc2: theta, z in (sigma is read a second time: not counted)
-        "k_wind": s * (nz + 8) * n_band,                   # p column, u, v, ws, wd in; ws, wd, thc, sb_con out (band cells)
+        # single domain: k_wind applies the thresholds and the state update; a band step leaves that to k_thc2
+        "k_thc": s * (2 * n + (0 if wind_final else 6 * n_band)),      # theta, z in (sigma's second read is not counted)
+        "k_wind": s * (nz + (8 if wind_final else 2)) * n_band,        # p column, u, v (+ ws, wd in; ws, wd, thc, sb_con out)
         "k_gz": 0,                                         # not launched on the default path
         "k_final": 0,
         "total": s * (5 * n + (nz + 7) * n_band),
@@ -227,7 +228,7 @@ def main():
 
     n_local = nx * (r1 - r0)
     n_band_local = int(band[r0:r1].sum())
-    ab = algorithmic_bytes(n_local, n_band_local, nz)
+    ab = algorithmic_bytes(n_local, n_band_local, nz, wind_final=(world == 1))
     knames = ("k_scan", "k_wind", "k_thc")
     dom = max(knames, key=lambda k: kern_ms[k])
     dom_gbs = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0

@@ -30,7 +30,9 @@
 // chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
 #define THC2_TX 32
 #define THC2_TY 64
+#ifndef THC2_NT
 #define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
+#endif
 
 // ------------------------------------------------------------------------------------
 // Global-memory search for cells whose window outgrows the LDS tile (rare).  Rings are

@@ -258,6 +258,34 @@ def test_search_radius_beyond_lds_halo_generic(hipctx, oracles):
         _assert_close64(a, b, nm)
 
 
+def test_wide_halo_path_matches_oracle(hipctx, oracles):
+    """A radius hint above 16 selects the LDS halo of 24 cells, which runs the separate
+    k_moments_final + k_gz + k_thc kernels (64-wide tiles) instead of k_thc2: same numbers."""
+    nx, ny, nz = 256, 192, 3
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat)
+    p3, p1 = synth.pressure_3d(st, nz, dt), synth.pressure_1d(nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    wo, wh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
+    hipctx.set_search_radius_hint(24)
+    try:
+        for tn in (1, 2):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p3, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+            hipctx.seabreeze_diag(7200.0, tn, p3, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+            oo = orc.diag(tn, p1, st.z, st.sigma, th, v, u, cdist, *wo)
+            oh = hipctx.diag(tn, p1, st.z, st.sigma, th, v, u, cdist, *wh)
+            for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+                _assert_close64(oh[k, :-1], oo[k, :-1], f"wide halo wrapper tn={tn} {nm}")
+    finally:
+        hipctx.set_search_radius_hint(16)
+    for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+        _assert_close64(a, b, f"wide halo generic {nm}")
+
+
 def test_no_band_and_one_class(hipctx):
     nx, ny, nz = 70, 20, 2
     dt = np.float64
