@@ -103,6 +103,7 @@ int pick_halo(const sb_ctx *c) {
     int r = c->radius_hint;
     if (r <= 8) return 8;
     if (r <= 16) return 16;
+    if (r <= 24) return 24;
     return SB_MAX_LDS_HALO;
 }
 
@@ -116,7 +117,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
-    const bool use_thc2 = H <= 16 && !getenv("SB_OLD_THC");
+    const bool use_thc2 = (H <= 16 || H == 32) && !getenv("SB_OLD_THC");
     int txw, tyrows;
     sb_thc_tile_shape(H, use_thc2, &txw, &tyrows);
     const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;

@@ -501,8 +501,8 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     static const bool old_thc = getenv("SB_OLD_THC") != nullptr;                  // k_gz + k_thc instead of k_thc2 (diagnostic)
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
-    // the fused second half (k_thc2) exists for LDS halos up to 16; wider windows keep k_gz + k_thc
-    const bool thc2 = H <= 16 && !old_thc;
+    // the fused second half (k_thc2) exists for LDS halos of 8, 16 and 32; 24 keeps k_gz + k_thc
+    const bool thc2 = (H <= 16 || H == 32) && !old_thc;
     // k_thc2 merges k_scan's moments itself; the f2py flavour needs the scalars earlier, for k_t0
     const bool merge_in_thc2 = thc2 && job.t0_fly && !gathered;
     hipError_t e = hipSuccess;

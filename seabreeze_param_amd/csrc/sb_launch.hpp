@@ -3,7 +3,7 @@
 #include "sb_device.hpp"
 
 #define SB_STATS_MAX_BLOCKS 2048
-#define SB_MAX_LDS_HALO 24          // largest LDS halo k_thc is instantiated for
+#define SB_MAX_LDS_HALO 32          // largest LDS halo a contrast kernel is instantiated for (k_thc2; 24: k_thc)
 #define SB_DIST_TY 4                 // rows per k_dist tile
 #define SB_PROF_EVENTS 8            // events one profiled diag call records
 #define SB_PROF_KERNELS 5           // k_scan, k_wind, k_t0/k_gz, k_thc, k_final_tiles

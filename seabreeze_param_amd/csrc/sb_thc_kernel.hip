@@ -30,6 +30,7 @@
 // chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
 #define THC2_TX 32
 #define THC2_TY 64
+#define THC2_TY32 16              // tile rows with a halo of 32: 81 x 97 table entries are what 160 KB of LDS hold
 #ifndef THC2_NT
 #define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
 #endif
@@ -1062,7 +1063,8 @@ hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *
     int nblocks = ncu;
     while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
     if (H <= 8) launch_thc2<T, THC2_TX, THC2_TY, 8>(job, nblocks, partials, nparts, stats_out, st);
-    else launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
+    else if (H <= 16) launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
+    else launch_thc2<T, THC2_TX, THC2_TY32, 32>(job, nblocks, partials, nparts, stats_out, st);   // H == 32
     return hipGetLastError();
 }
 template hipError_t sb_launch_thc2<float>(const DiagJob<float> &, int, int, const Moments *, int, float *, hipStream_t);
@@ -1078,6 +1080,7 @@ static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_
 int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }
 void sb_thc_tile_shape(int H, bool thc2, int *tx, int *ty) {
     if (thc2 && H <= 16) { *tx = THC2_TX; *ty = THC2_TY; }
+    else if (thc2 && H == 32) { *tx = THC2_TX; *ty = THC2_TY32; }
     else { *tx = 64; *ty = sb_thc_tile_rows(H); }
 }
 

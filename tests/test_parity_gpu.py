@@ -258,6 +258,39 @@ def test_search_radius_beyond_lds_halo_generic(hipctx, oracles):
         _assert_close64(a, b, nm)
 
 
+def test_halo_32_holds_radii_up_to_32_in_lds(hipctx, oracles):
+    """Windows of up to 32 cells (the N2560 grid needs 31) stay on the LDS path of k_thc2's 32 x 16
+    tiles: same numbers as the oracle, and no cell on the global-memory path."""
+    nx, ny, nz = 256, 192, 2
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=20000.0, kwin=27)
+    cdist = np.where(np.abs(cdist) < 12000.0, np.sign(cdist) * np.minimum(np.abs(cdist), 179.0), cdist)
+    p3, p1 = synth.pressure_3d(st, nz, dt), synth.pressure_1d(nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    wo, wh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
+    hipctx.set_search_radius_hint(30)
+    try:
+        for tn in (1, 2):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p3, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+            hipctx.seabreeze_diag(7200.0, tn, p3, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+            nn_generic = orc.last_nn_max
+            c = hipctx.last_counters()
+            assert c["global_path_cells"] == 0 and c["max_radius"] == nn_generic, (c, nn_generic)
+            oo = orc.diag(tn, p1, st.z, st.sigma, th, v, u, cdist, *wo)
+            oh = hipctx.diag(tn, p1, st.z, st.sigma, th, v, u, cdist, *wh)
+            for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+                _assert_close64(oh[k, :-1], oo[k, :-1], f"halo 32 wrapper tn={tn} {nm}")
+    finally:
+        hipctx.set_search_radius_hint(16)
+    assert 24 < nn_generic <= 32, nn_generic
+    for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+        _assert_close64(a, b, f"halo 32 generic {nm}")
+
+
 def test_wide_halo_path_matches_oracle(hipctx, oracles):
     """A radius hint above 16 selects the LDS halo of 24 cells, which runs the separate
     k_moments_final + k_gz + k_thc kernels (64-wide tiles) instead of k_thc2: same numbers."""
