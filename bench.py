@@ -78,7 +78,7 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0):
+def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0, prec=8):
     """Time the CPU oracle (our Fortran restatement of the reference, `kind: port`) on
     this box's host cores: serial and all-core OpenMP, bounded by budget_s each."""
     from oracle.pyoracle import Oracle        # checker / baseline only
@@ -88,8 +88,8 @@ def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0):
     for name, omp in (("serial", False), ("omp", True)):
         if omp:
             os.environ["OMP_NUM_THREADS"] = str(ncores)
-        orc = Oracle(8, omp=omp)
-        state = [np.zeros((ny, nx)) for _ in range(4)]
+        orc = Oracle(prec, omp=omp)
+        state = [np.zeros((ny, nx), p.dtype) for _ in range(4)]
         times = []
         t_all = time.perf_counter()
         tn = 1
@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--nx", type=int, default=2560)
     ap.add_argument("--ny", type=int, default=1920)
     ap.add_argument("--nz", type=int, default=56)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="working precision (BASELINE configs[3], the N2560 grid, is quoted in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline per variant")
     ap.add_argument("--comm", choices=("native", "torch", "gloo"), default="native",
@@ -148,7 +150,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     nx, ny, nz = args.nx, args.ny, args.nz
-    dt = np.float64
+    dt = np.float64 if args.dtype == "f64" else np.float32
+    esz = 8 if args.dtype == "f64" else 4
     K, W = args.steps, args.warmup
 
     # ---- synthetic inputs (host, deterministic), shared by GPU and CPU baseline --------
@@ -181,7 +184,7 @@ def main():
     u_full, v_full = synth.wind_step(st, nz, 1, dt, rows=rows)
     gen_s = time.perf_counter() - t_gen
 
-    runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1,
+    runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1, dtype=dt,
                         comm=comm if world > 1 else "torch")
     runner.upload_static(st.z, st.sigma, cdist)
     # two input sets at different addresses: B swaps u and v (distinct synthetic winds) and
@@ -228,7 +231,7 @@ def main():
 
     n_local = nx * (r1 - r0)
     n_band_local = int(band[r0:r1].sum())
-    ab = algorithmic_bytes(n_local, n_band_local, nz, wind_final=(world == 1))
+    ab = algorithmic_bytes(n_local, n_band_local, nz, s=esz, wind_final=(world == 1))
     knames = ("k_scan", "k_wind", "k_thc")
     dom = max(knames, key=lambda k: kern_ms[k])
     dom_gbs = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
@@ -245,10 +248,10 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"seabreeze_diag generic flavour, N{nx // 2} ({nx}x{ny}) global grid, nz={nz}, fp64 "
+            "workload": f"seabreeze_diag generic flavour, N{nx // 2} ({nx}x{ny}) global grid, nz={nz}, {'fp64' if esz == 8 else 'fp32'} "
                         f"(BASELINE.json configs[2])",
             "nx": nx, "ny": ny, "nz": nz,
             "band_fraction": n_band_total / (nx * ny),
@@ -275,7 +278,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ncores = cpu_baseline(st, cdist, p_full, u_full, v_full, theta_a, nz, args.cpu_budget)
+        cb, ncores = cpu_baseline(st, cdist, p_full, u_full, v_full, theta_a, nz, args.cpu_budget, prec=esz)
         result["cpu_baseline"] = {
             "value": nx * ny / cb["omp"]["s_per_call"],
             "unit": "grid-points/s",
