@@ -344,7 +344,7 @@ def test_no_band_and_one_class(hipctx):
 # ----------------------------------------------------------------------------------------
 # size-independent properties at BASELINE sizes (no oracle needed)
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1024, 768, 8), (2560, 1920, 4)])
+@pytest.mark.parametrize("shape", [(1024, 768, 8), (2560, 1920, 4), (5120, 3840, 2)])   # BASELINE configs[1..3]
 def test_properties_at_full_size(hipctx, shape):
     nx, ny, nz = shape
     dt = np.float64
