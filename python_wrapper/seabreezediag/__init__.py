@@ -32,10 +32,10 @@ __all__ = ["diag", "c2f", "read_nc"]
 
 
 def c2f(array):
-    """Reinterpret a C-ordered array as the Fortran-ordered array with reversed shape
-    (for a C-contiguous input this is the transpose view, no copy)."""
-    array = np.asarray(array)
-    return array.ravel().reshape(array.shape[::-1], order="F")
+    """Reinterpret a C-ordered array as the Fortran-ordered array with reversed shape.  Element for
+    element that is the transpose whatever the memory layout of the input (ravel in C order, refill in
+    Fortran order), so the transpose *view* is returned: no copy for C- or Fortran-contiguous input."""
+    return np.asarray(array).T
 
 
 def _pop(kwargs, key, default=None):
@@ -48,19 +48,16 @@ _dist_cache = {"key": None, "dist": None}
 def _coast_distance(lsm, ice, lon, lat):
     """Signed coast distance for this land mask and sea-ice field.  The reference recomputes it at
     every timestep (ref :223-228); the result depends only on these four inputs, so the last one is
-    kept and reused while their bytes are unchanged -- sea ice in reanalysis
-    files changes daily, not with every model step."""
-    import hashlib
-
-    h = hashlib.blake2b(digest_size=16)
-    for a in (lsm, ice, lon, lat):
-        a = np.ascontiguousarray(a)
-        h.update(str(a.dtype).encode() + str(a.shape).encode())
-        h.update(a.view(np.uint8).reshape(-1).data)
-    key = h.digest()
-    if _dist_cache["key"] != key:
+    kept and reused while they compare equal to the copies kept with it --
+    sea ice in reanalysis files changes daily, not with every model step.  An exact comparison
+    (a memcmp-speed pass) rather than a digest: cheaper, and no collision to argue about."""
+    key = _dist_cache["key"]
+    same = key is not None and all(
+        a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+        for a, b in zip((np.asarray(lsm), np.asarray(ice), np.asarray(lon), np.asarray(lat)), key))
+    if not same:
         _dist_cache["dist"] = c2f(get_dist(get_edges(c2f(lsm), c2f(ice)), c2f(lsm), lon, lat))
-        _dist_cache["key"] = key
+        _dist_cache["key"] = tuple(np.array(a, copy=True) for a in (lsm, ice, lon, lat))
     return _dist_cache["dist"]
 
 
@@ -92,25 +89,33 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
                 warnings.warn(f"{names[key]} should be given from previous timestep")
             val = np.zeros_like(lsm)
         state[key] = val
-    ws, wd, thc = state["ws"], state["wd"], state["thc"]
+    # The kernels update windspeed / winddir / thc in place (ref: seabreeze_diag_python.f90:237-239,
+    # 268-273) and f2py hands Fortran-contiguous float32 arrays through without a copy, so the state is
+    # kept in private arrays: the caller's arrays (e.g. what an earlier call returned) are never written.
+    # thc is write-only in the kernel: one scratch plane serves every step.
+    ws, wd = (np.array(state[k], dtype=np.float32, order="C") for k in ("ws", "wd"))
+    thc = np.empty_like(ws)
 
     has_time = np.ndim(v) > 3
     nt = len(v) if has_time else 1
     nlat, nlon = np.shape(t)[-2:]
-    out_all = np.zeros([4, nt, nlat, nlon])
+    sb_all = np.zeros([nt, nlat, nlon])           # float64 like the reference's (ref :214)
     dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
+    t0 = thc
     for ts in range(nt):
         if ci is not None:
             ice = ci[ts] if has_time else ci
             ice = ice.filled(0) if hasattr(ice, "filled") else ice
-            dist = _coast_distance(lsm, ice, lon, lat)       # recomputed every step like the reference (:223-228)
+            dist = _coast_distance(lsm, ice, lon, lat)       # the reference recomputes it every step (:223-228); here: when ice changes
         tk, vk, uk = (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
         out = c2f(_diag_kernel(tt, c2f(pres), c2f(z), c2f(std), c2f(tk), c2f(vk), c2f(uk), c2f(dist),
                                c2f(ws), c2f(wd), c2f(thc), **kwargs))
-        out_all[:, ts] = out
-        thc, ws, wd = out[1], out[2], out[3]
+        sb_all[ts] = out[0]
+        t0, ws, wd = out[1], out[2], out[3]              # views: the next step reads them where they lie
         tt += 1
-    return tt, out_all[0], thc, ws, wd
+    # what the reference returns as "thc" is the t0 plane (ref :244); copies, so that the arrays handed out
+    # do not alias the (4-plane) output buffer of the last step
+    return tt, sb_all, np.array(t0), np.array(ws), np.array(wd)
 
 
 def read_nc(fnv, fnu, fntheta, fnci, vv="v", vu="u", vtheta="t2m", vci="ci", vpres="pres", vtime="time"):

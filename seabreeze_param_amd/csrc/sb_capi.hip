@@ -378,12 +378,20 @@ int diag_host(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T 
     T *dv = s.in(v + (size_t)lev * n2, n2), *du = s.in(u + (size_t)lev * n2, n2), *dcd = s.in(cdist, n2);
     nps = 1;
     T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2);
-    T *dout = s.in(output, 4 * n2);          // row nlats is left as the caller passed it
+    T *dout = s.out<T>(4 * n2);              // nothing to upload: the kernels write rows 1..nlats-1 of every plane
     if (s.rc) return s.rc;
     rc = diag_dev<T>(c, tn, dp, dz, dsd, dth, dv, du, dcd, dws, dwd, dthc, target_plev, thresh_wind, thresh_winddir,
                      thresh_windch, thresh_thc, target_time, maxdist, timestep, nps, nlons, nlats, dout, nullptr);
     if (rc) return rc;
-    s.back(ws, dws, n2); s.back(wd, dwd, n2); s.back(thc, dthc, n2); s.back(output, dout, 4 * n2);
+    // Only what the call changed travels back.  windspeed / winddir change on the first step and on the
+    // steps the target_time branch fires (ref :268-273), thc at the band cells of every step; row nlats
+    // of the output planes is never written (ref :165) and stays as the caller passed it.
+    const T dt_s = timestep * T(60.), period = target_time * (T(60.) * T(60.));
+    const bool refresh = sb_modulo<T>((T)tn * dt_s, period) < T(0.0001);
+    if (refresh || tn < 2) { s.back(ws, dws, n2); s.back(wd, dwd, n2); }
+    s.back(thc, dthc, n2);
+    const size_t nwritten = (size_t)nlons * (nlats > 0 ? nlats - 1 : 0);
+    for (int pl = 0; pl < 4 && nwritten > 0; ++pl) s.back(output + (size_t)pl * n2, dout + (size_t)pl * n2, nwritten);
     return s.finish();
 }
 
