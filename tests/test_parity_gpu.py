@@ -184,6 +184,29 @@ def test_wrapper_flavour_fp32(hipctx, oracles, shape):
         assert np.max(np.abs(oh[0, :-1][ok] - oo[0, :-1][ok])) < 5e-3
 
 
+@pytest.mark.parametrize("shape", [(96, 72, 3), (256, 192, 4)])
+def test_generic_flavour_fp32(hipctx, oracles, shape):
+    """Host-model flavour in single precision (what `bench.py --dtype f32` and BASELINE configs[3] run):
+    winds to 2e-6, thc to the reference's own fp32 window-sum noise, sb_con away from the knife edge."""
+    nx, ny, nz = shape
+    dt, orc = np.float32, oracles[4]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=700.0)
+    cdist = np.where(np.abs(cdist) < 12000.0, np.sign(cdist) * np.minimum(np.abs(cdist), 179.0), cdist).astype(dt)
+    p = synth.pressure_3d(st, nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    for tn in range(1, 4):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+        hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        assert relerr(sh[0], so[0], floor=1e-3) < 2e-6 and relerr(sh[1], so[1], floor=1e-1) < 2e-5, tn
+        assert np.max(np.abs(sh[2] - so[2])) < 2e-3, tn
+        near = np.abs(np.abs(so[2]) - 0.75) < 5e-3
+        assert np.max(np.abs(sh[3][~near] - so[3][~near])) < 5e-3, tn
+
+
 # ----------------------------------------------------------------------------------------
 # halo'd (band) arrays, search radius beyond the LDS tile, degenerate grids
 # ----------------------------------------------------------------------------------------
