@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
 //            -> flag of the k_thc tile(s) the segment's band cells fall in
 //            -> fill value outside the band           ref :176 / seabreeze_diag_python.f90:173,279-280
 // ------------------------------------------------------------------------------------
-template <typename T, int SPT>
-__global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__restrict__ partials,
-                                                   int do_stats) {
+template <typename T, int SPT, bool WR, bool ST>      // WR: f2py flavour; ST: accumulate sigma's moments
+__global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__restrict__ partials) {
+    constexpr bool wrapper = WR, do_stats = ST;
     const Geo g = job.g;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int NWV = STATS_NT / SB_WAVE;              // waves per workgroup; SPT segments per trip
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     // wave gets floor or ceil of nseg/W segments, and neighbouring waves read neighbouring memory
     const unsigned nwaves = gridDim.x * NWV;
     const size_t pl = (size_t)g.nx * g.ny;
-    const bool wrapper = job.flavour == SB_FLAVOUR_WRAPPER;
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
     int cnt = 0;
@@ -218,14 +217,18 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 job.bandbits[seg] = wb;
             }
             if (wb) {                                            // wave-uniform
-                // the tile columns the segment's band cells fall in: two or three of them (one more when
-                // the ghost width is not a multiple of the tile width)
-                const int txs = job.thc_txs;
-                const int tA = ((int)(t.W[q] * 64u) - g.h) >> txs;
-                const int trow = (yi / job.thc_ty) * job.thc_ntx;
-                for (int j = 0; j <= (64 >> txs); ++j) {
-                    const uint64_t mj = __ballot(band && (xi >> txs) == tA + j);
-                    if (mj && lane == 0) job.tile_nnmax[trow + tA + j] = 1;    // plain stores of 1: benign duplicates
+                // the tile columns the segment's band cells fall in (two of 32 cells, three when the ghost
+                // width is not a multiple of the tile width): lane j looks at the bits of column tA + j
+                // in the ballot and raises that tile's flag -- one exec-masked store, no further ballots
+                const int txs = job.thc_txs, tw = 1 << txs;
+                const int xi0 = (int)(t.W[q] * 64u) - g.h;       // interior longitude of lane 0 (may be negative)
+                const int tA = xi0 >> txs;
+                int lo = ((tA + lane) << txs) - xi0, hi = lo + tw;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > 64 ? 64 : hi;
+                if (lane <= (64 >> txs) && lo < hi) {
+                    const uint64_t m = (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+                    if (wb & m) job.tile_nnmax[(yi / job.thc_ty) * job.thc_ntx + tA + lane] = 1;   // benign duplicates
                 }
             }
             if (interior && yi < g.rows && !band) {
@@ -492,6 +495,17 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
     return hipGetLastError();
 }
 
+// k_scan is instantiated per flavour and with/without the statistics, so that neither is a branch in its
+// (issue-bound) segment loop
+template <typename T>
+static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool stats, hipStream_t st) {
+    const bool wr = job.flavour == SB_FLAVOUR_WRAPPER;
+    if (wr && stats) hipLaunchKernelGGL((k_scan<T, 2, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (wr) hipLaunchKernelGGL((k_scan<T, 2, true, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (stats) hipLaunchKernelGGL((k_scan<T, 2, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else hipLaunchKernelGGL((k_scan<T, 2, false, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+}
+
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     const Geo &g = job.g;
@@ -516,10 +530,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     // before its ghost rows arrive, so there k_thc2 applies them.
     if (job.wind_final && ph2) {
         if (ev) { (void)hipEventRecord(ev[0], st); }
-        static const int spt0 = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 2;   // tuning knob (diagnostic)
-        if (spt0 <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
-        else if (spt0 <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
-        else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, 1);
+        launch_scan<T>(job, nblk, lc.partials, true, st);
         if (!merge_in_thc2)
             hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
                                (Moments *)nullptr);
@@ -546,10 +557,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     if (ph1) {
         // k_scan (+ merge of the statistics when they are this domain's own and k_thc2 does not do it)
         if (ev) (void)hipEventRecord(ev[0], st);
-        static const int spt = getenv("SB_SCAN_SPT") ? atoi(getenv("SB_SCAN_SPT")) : 2;   // tuning knob (diagnostic)
-        if (spt <= 2) hipLaunchKernelGGL((k_scan<T, 2>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
-        else if (spt <= 3) hipLaunchKernelGGL((k_scan<T, 3>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
-        else hipLaunchKernelGGL((k_scan<T, 5>), dim3(nblk), dim3(STATS_NT), 0, st, job, lc.partials, gathered ? 0 : 1);
+        launch_scan<T>(job, nblk, lc.partials, !gathered, st);
         if (!gathered && !merge_in_thc2)
             hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
                                (Moments *)nullptr);
