@@ -32,6 +32,7 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
+    int tile_rows = 0;          // 0: automatic; 32 / 64: forced k_thc2 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
     // workspace (grow-only)
     DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd, coastbits;
@@ -119,7 +120,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const int H = pick_halo(c);
     const bool use_thc2 = (H <= 16 || H == 32) && !getenv("SB_OLD_THC");
     int txw, tyrows;
-    sb_thc_tile_shape(H, use_thc2, &txw, &tyrows);
+    sb_thc_tile_shape(H, use_thc2, g.nx, g.rows, c->ncu, &txw, &tyrows);
+    if (use_thc2 && H > 8 && H <= 16 && c->tile_rows) tyrows = c->tile_rows;
     const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
     // raises flags in this call's buffer, k_final clears the other one for the next call, so no
@@ -684,6 +686,13 @@ int sb_set_search_radius_hint(sb_ctx *c, int radius) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (radius < 1) return fail(c, SB_ERR_ARG, "radius must be >= 1");
     c->radius_hint = radius;
+    return SB_OK;
+}
+
+int sb_set_tile_rows(sb_ctx *c, int rows) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (rows != 0 && rows != 32 && rows != 64) return fail(c, SB_ERR_ARG, "tile rows must be 0, 32 or 64");
+    c->tile_rows = rows;
     return SB_OK;
 }
 

@@ -29,7 +29,7 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
 int sb_thc_tile_rows(int H);
-void sb_thc_tile_shape(int H, bool thc2, int *tx, int *ty);         // tile size of the contrast kernel that will run                                         // k_thc tiles are 64 x this many cells
+void sb_thc_tile_shape(int H, bool thc2, int nx, int rows, int ncu, int *tx, int *ty);         // tile size of the contrast kernel that will run                                         // k_thc tiles are 64 x this many cells
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse_final, hipStream_t st);
 // the fused second half (H <= 16): partials/nparts: k_scan's moments to merge (0: read job.stats)

@@ -30,6 +30,8 @@
 // chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
 #define THC2_TX 32
 #define THC2_TY 64
+#define THC2_TYS 32               // small grids (a band of a multi-GPU run, N512): half-height tiles, so that more
+                                  // of the one-workgroup-per-CU grid has a tile and each tile is shorter
 #define THC2_TY32 16              // tile rows with a halo of 32: 81 x 97 table entries are what 160 KB of LDS hold
 #ifndef THC2_NT
 #define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
@@ -1063,6 +1065,7 @@ hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *
     int nblocks = ncu;
     while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
     if (H <= 8) launch_thc2<T, THC2_TX, THC2_TY, 8>(job, nblocks, partials, nparts, stats_out, st);
+    else if (H <= 16 && job.thc_ty == THC2_TYS) launch_thc2<T, THC2_TX, THC2_TYS, 16>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 16) launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
     else launch_thc2<T, THC2_TX, THC2_TY32, 32>(job, nblocks, partials, nparts, stats_out, st);   // H == 32
     return hipGetLastError();
@@ -1078,8 +1081,15 @@ static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_
 }
 
 int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }
-void sb_thc_tile_shape(int H, bool thc2, int *tx, int *ty) {
-    if (thc2 && H <= 16) { *tx = THC2_TX; *ty = THC2_TY; }
+void sb_thc_tile_shape(int H, bool thc2, int nx, int rows, int ncu, int *tx, int *ty) {
+    if (thc2 && H <= 16) {
+        *tx = THC2_TX;
+        *ty = THC2_TY;
+        // about a quarter of the tiles touch the coastal band: while even twice the full-height tile count
+        // would leave workgroups without a tile, use the half-height tiles (H = 16 only)
+        const long long full = (long long)((nx + THC2_TX - 1) / THC2_TX) * ((rows + THC2_TY - 1) / THC2_TY);
+        if (H > 8 && full <= 2LL * ncu) *ty = THC2_TYS;
+    }
     else if (thc2 && H == 32) { *tx = THC2_TX; *ty = THC2_TY32; }
     else { *tx = 64; *ty = sb_thc_tile_rows(H); }
 }

@@ -107,7 +107,7 @@ SHAPES = [(96, 72, 3), (256, 192, 5), (130, 75, 2), (63, 40, 1), (200, 33, 4), (
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-def test_wrapper_flavour_fp64(hipctx, oracles, shape):
+def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
     nx, ny, nz = shape
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt, fractional_coast=True)
@@ -132,9 +132,18 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
+@pytest.fixture(params=[64, 32], ids=["tiles32x64", "tiles32x32"])
+def tile_rows(request, hipctx):
+    """Both heights of the contrast kernel's LDS tiles: by default small grids get the 32-row tiles and
+    the benchmark grid the 64-row ones, so the oracle comparisons run under each."""
+    hipctx.set_tile_rows(request.param)
+    yield request.param
+    hipctx.set_tile_rows(0)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("bnd", [hip.SB_BND_GLOBAL, hip.SB_BND_WRAPPER])
-def test_generic_flavour_fp64(hipctx, oracles, shape, bnd):
+def test_generic_flavour_fp64(hipctx, oracles, shape, bnd, tile_rows):
     nx, ny, nz = shape
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)
@@ -210,7 +219,7 @@ def test_generic_flavour_fp32(hipctx, oracles, shape):
 # ----------------------------------------------------------------------------------------
 # halo'd (band) arrays, search radius beyond the LDS tile, degenerate grids
 # ----------------------------------------------------------------------------------------
-def test_halo_mode_matches_oracle(hipctx, oracles):
+def test_halo_mode_matches_oracle(hipctx, oracles, tile_rows):
     nx, ny, nz, h = 160, 96, 3, 7
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx + 2 * h, ny + 2 * h, dt)          # a bigger field whose rim serves as ghosts
