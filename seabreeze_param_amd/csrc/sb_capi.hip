@@ -143,6 +143,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.stats = (const T *)c->stats;
     job.tile_nnmax = flags_now;
     job.counters = flags_now + (size_t)tx * ty;
+    { static const bool stat = getenv("SB_THC_STATIC") != nullptr;    // diagnostic: static split of the tile list
+      job.ticket = stat ? nullptr : (int *)c->ticket; }
     job.next_flags = flags_next;
     job.next_flags_n = nflag;
     // this call's wind speed / direction at band cells (k_wind -> k_final)

@@ -160,6 +160,7 @@ struct DiagJob {
     int thc_ty, thc_ntx, thc_nty;   // contrast-kernel tile rows and tile-grid shape
     int thc_txs;                    // log2 of the tile width (6: 64 longitudes, k_thc; 5: 32, k_thc2)
     int *tile_nnmax;                // per thc tile: 0 = no band cell; k_prep raises 1, k_thc leaves the largest radius
+    int *ticket;                    // k_thc2 draws list positions from it; k_scan zeroes it (nullptr: static split)
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
     long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock stamps per thc tile
 };

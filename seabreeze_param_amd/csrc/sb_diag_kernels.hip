@@ -149,6 +149,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     // wave gets floor or ceil of nseg/W segments, and neighbouring waves read neighbouring memory
     const unsigned nwaves = gridDim.x * NWV;
     const size_t pl = (size_t)g.nx * g.ny;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && job.ticket) *job.ticket = 0;   // k_thc2's tile dealing starts over
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
     int cnt = 0;

@@ -132,6 +132,47 @@ __device__ __forceinline__ void thc_list_lookup(int ch, int base, int c, int inc
     }
 }
 
+// Dynamic dealing (grids of at most one chunk = 4096 tiles): the ballots of the tile flags stay in LDS for
+// the whole kernel and every wave keeps (count, inclusive prefix) of entry `lane`, so that any wave can turn
+// a position of the row-major list of active tiles into a tile with thc_pos_to_tile.  Returns the number of
+// active tiles.  Two barriers.
+template <int NT>
+__device__ __forceinline__ int thc_list_dynamic_init(const int *__restrict__ flags, int ntiles, int *s_wcnt,
+                                                     unsigned long long *s_bm, const int *pre, int &c, int &incl) {
+    constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int t = k * NT + tid;
+        const int v = pre ? pre[k] : flags[t < ntiles ? t : ntiles - 1];
+        const uint64_t bm = __ballot(t < ntiles && v != 0);
+        if (lane == 0) { s_wcnt[k * NWV + wv] = __popcll(bm); s_bm[k * NWV + wv] = bm; }
+    }
+    __syncthreads();
+    c = lane < NE ? s_wcnt[lane] : 0;
+    incl = sb_wave_scan_add(c);
+    __syncthreads();
+    return __shfl(incl, SB_WAVE - 1);
+}
+
+// the tile at position pos (< number of active tiles) of the list; wave-uniform, every lane takes part
+template <int NT>
+__device__ __forceinline__ int thc_pos_to_tile(int pos, int c, int incl, const unsigned long long *s_bm) {
+    constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;
+    const int lane = threadIdx.x & 63;
+    const uint64_t hit = __ballot(lane < NE && pos >= incl - c && pos < incl);
+    const int e = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
+    int nth = pos - (__shfl(incl, e) - __shfl(c, e));        // which set bit of that entry's ballot
+    const uint64_t bm = s_bm[e];
+    int bit = 0;
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) {                       // select the nth set bit: halve the range six times
+        const int cnt = __popcll((bm >> bit) & ((1ull << w) - 1ull));
+        if (nth >= cnt) { nth -= cnt; bit += w; }
+    }
+    return (e / NWV) * NT + (e % NWV) * SB_WAVE + bit;
+}
+
 // The ordered list of active tiles this workgroup owns -> s_mine[0..n).  s_wcnt: 64 ints, s_bm: 64
 // ballot words.  A chunk is K * NT = 64 * 64 tiles whose flags are all loaded at once; `pre`: the flags of
 // chunk 0 already loaded by thc_list_preload (issued early, so that other work hides the round trip), or
@@ -657,7 +698,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
     __shared__ T s_stats[4];
     __shared__ unsigned long long s_bmw[SB_WAVE];
     __shared__ unsigned short s_glob[TX * TY];   // cells whose window outgrows the tile (rare): handled after T4
-    __shared__ int s_nglob;
+    __shared__ int s_nglob, s_next;
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -719,12 +760,27 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
             }
         }
     }
-    const int nmine = thc_build_list<NT>(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw, preflags);   // has barriers
+    // Tiles are dealt dynamically when the flags fit one chunk (<= 4096 tiles): workgroup b starts with list
+    // position b and draws further positions from a ticket (k_scan zeroes it) while it works, so that the
+    // cost of a tile -- one to four search rounds, by its number of band cells -- evens out; the neighbours in
+    // the list are then in flight on neighbouring workgroups at the same time.  Larger grids keep the static,
+    // XCD-aware split of the list (s_mine).
+    const bool dyn = ntiles <= (SB_WAVE / NWV) * NT && job.ticket != nullptr;
+    int nmine = 0, nactive = 0, e_c = 0, e_incl = 0, tile = -1;
+    if (dyn) {
+        nactive = thc_list_dynamic_init<NT>(job.tile_nnmax, ntiles, s_wcnt, s_bmw, preflags, e_c, e_incl);
+        if ((int)blockIdx.x < nactive) tile = thc_pos_to_tile<NT>((int)blockIdx.x, e_c, e_incl, s_bmw);
+    } else {
+        nmine = thc_build_list<NT>(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw, preflags);   // has barriers
+        if (nmine > 0) tile = s_mine[0];
+    }
+    const int first_tile = tile;
+    (void)first_tile;                          // used by the diagnostic build only
 #ifdef SB_STAMPS
     const long long t_list = clock64();
 #endif
     ThcRegs<T, NC, NCH, FLY> R;
-    if (nmine > 0) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, s_mine[0], R);
+    if (tile >= 0) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, tile, R);
     SB_PSTAMP(1);
     for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
@@ -741,19 +797,21 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
     __syncthreads();
 
 #ifdef SB_STAMPS
-    if (tid == 0 && nmine > 0) {       // prologue of this workgroup, kept with its first tile
-        long long *st = job.stamps + (size_t)s_mine[0] * SB_NSTAMP;
+    if (tid == 0 && first_tile >= 0) {       // prologue of this workgroup, kept with its first tile
+        long long *st = job.stamps + (size_t)first_tile * SB_NSTAMP;
         st[8] = w_begin;                       // 100 MHz wall clock at this workgroup's first instruction
         st[9] = clock64() - t_begin;           // whole prologue, shader cycles
         st[10] = t_list - t_begin;             // tile list
         for (int i = 0; i < 6; ++i) st[16 + i] = t_pro[i];
     }
-    if (lane == 0 && nmine > 0 && wv == NWV - 1)   // when did the last wave of the workgroup start?
-        job.stamps[(size_t)s_mine[0] * SB_NSTAMP + 12] = w_begin;
+    if (lane == 0 && first_tile >= 0 && wv == NWV - 1)   // when did the last wave of the workgroup start?
+        job.stamps[(size_t)first_tile * SB_NSTAMP + 12] = w_begin;
 #endif
-    for (int mi = 0; mi < nmine; ++mi) {
-        const int tile = s_mine[mi];
+    for (int mi = 0; tile >= 0; ++mi) {
         const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
+        // the position of the tile after this one: drawn now, it is back long before it is needed
+        int next_pos = 0;
+        if (dyn && tid == 0) next_pos = (int)gridDim.x + atomicAdd(job.ticket, 1);
         SB_STAMP(0);
         // ---- T0: compact the tile's band cells, issue their state loads ----------------------
         if (tid < TY) {
@@ -863,9 +921,15 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
             ownbits |= ((ownw[q] >> ((x0 + (cc & 63) + g.h) & 31)) & 1u) << q;
         }
         asm volatile("" : "+v"(ownbits));        // materialise here: the compiler would sink this into T4
-        // the next tile's loads fly under T2..T4 (and under the other workgroups' staging)
-        if (mi + 1 < nmine) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, s_mine[mi + 1], R);
+        if (dyn && tid == 0) s_next = next_pos;
         lds_barrier();
+        // the next tile's loads fly under T2..T4 (and under the other workgroups' staging)
+        int next_tile = -1;
+        if (dyn) {
+            const int np = s_next;                               // read by everyone before the next write (4 barriers on)
+            if (np < nactive) next_tile = thc_pos_to_tile<NT>(np, e_c, e_incl, s_bmw);
+        } else if (mi + 1 < nmine) next_tile = s_mine[mi + 1];
+        if (next_tile >= 0) thc2_issue<T, TX, TY, H, FLY, RPW, NCH>(job, next_tile, R);
         SB_STAMP(2);
         // ---- T2: exclusive prefix of the band totals along latitude ------------------------------
         for (int t = tid; t < 3 * W; t += NT) {
@@ -1043,9 +1107,10 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
         SB_STAMP(5);
         // no barrier here: the next tile's T0 touches only s_word / s_cell / s_nglob (all read before
         // the barrier above), and its two barriers stand between this search and the next table write
+        tile = next_tile;
     }
 #ifdef SB_STAMPS
-    if (tid == 0 && nmine > 0) job.stamps[(size_t)s_mine[0] * SB_NSTAMP + 11] = wall_clock64();
+    if (tid == 0 && first_tile >= 0) job.stamps[(size_t)first_tile * SB_NSTAMP + 11] = wall_clock64();
 #endif
 }
 
