@@ -96,8 +96,8 @@ int  sb_synchronize(sb_ctx *ctx);
 /* Per-kernel timing with HIP events on the stream(s) the kernels run on.  Between
    sb_profile_begin and sb_profile_end the first `max_calls` diag calls record events around
    their launches; sb_profile_end synchronises and returns the average duration in ms of
-   [0] k_scan (+ k_moments_final where it is still a launch) [1] k_wind [2] k_t0 (f2py flavour) or k_gz
-   (legacy path); empty on the default host-model path [3] k_thc2 (k_thc on the legacy path) [4] unused. */
+   [0] k_scan (+ k_moments_final where it is still a launch) [1] k_wind [2] k_t0 (f2py flavour; empty for
+   the host-model flavour) [3] k_thc2 [4] unused.                                                        */
 int  sb_profile_begin(sb_ctx *ctx, int max_calls);
 int  sb_profile_end(sb_ctx *ctx, double avg_ms[5], int *ncalls);
 

@@ -118,10 +118,9 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
-    const bool use_thc2 = (H <= 16 || H == 32) && !getenv("SB_OLD_THC");
     int txw, tyrows;
-    sb_thc_tile_shape(H, use_thc2, g.nx, g.rows, c->ncu, &txw, &tyrows);
-    if (use_thc2 && H > 8 && H <= 16 && c->tile_rows) tyrows = c->tile_rows;
+    sb_thc_tile_shape(H, g.nx, g.rows, c->ncu, &txw, &tyrows);
+    if (H > 8 && H <= 16 && c->tile_rows) tyrows = c->tile_rows;
     const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
     // raises flags in this call's buffer, k_final clears the other one for the next call, so no
@@ -147,18 +146,24 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
       job.ticket = stat ? nullptr : (int *)c->ticket; }
     job.next_flags = flags_next;
     job.next_flags_n = nflag;
-    // this call's wind speed / direction at band cells (k_wind -> k_final)
-    if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
-    if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
-    job.nws = (T *)c->nws.p;
-    job.nwd = (T *)c->nwd.p;
-    // the host-model flavour derives t0 inside k_thc; the f2py flavour returns the t0 plane
+    // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc2)
+    job.nws = job.nwd = nullptr;
+    if (!(phases == 3 && !c->gathered)) {
+        if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
+        if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
+        job.nws = (T *)c->nws.p;
+        job.nwd = (T *)c->nwd.p;
+    }
+    // the host-model flavour derives t0 inside k_thc2; the f2py flavour returns the t0 plane
     job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
     // whole single-domain calls on the k_thc2 path: contrast first, k_wind applies the update
-    job.wind_final = (phases == 3 && !c->gathered && use_thc2) ? 1 : 0;
-    // one workspace field: t0 itself (f2py flavour) or gz = (gmma*z)*sigmoid(sigma) (host-model flavour)
-    if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
-    job.t0 = (T *)c->t0.p;
+    job.wind_final = (phases == 3 && !c->gathered) ? 1 : 0;
+    // the t0 plane with its ghost cells: f2py flavour only (k_t0 -> k_thc2)
+    job.t0 = nullptr;
+    if (!job.t0_fly) {
+        if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
+        job.t0 = (T *)c->t0.p;
+    }
     job.stamps = nullptr;
 #ifdef SB_STAMPS
     if ((rc = ensure(c, c->stamps, (size_t)tx * ty * SB_NSTAMP * sizeof(long long)))) return rc;
@@ -227,7 +232,7 @@ int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream)
 
 // One model step of a latitude band: the communication (sigma moments all-gather, theta ghost
 // rows) runs on the context's second stream while k_scan and k_wind, which need neither, run
-// on the caller's stream; the two join before the statistics merge, k_gz and k_thc.
+// on the caller's stream; the two join before the statistics merge and k_thc2.
 template <typename T>
 int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, const T *p, const T *u,
                   const T *v, T *theta, const T *mask, const T *z, const T *sigma, T *ws, T *wd, T *thc, T *sb_con,
@@ -666,7 +671,7 @@ int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
     HIPCHK(c, hipDeviceSynchronize());
-    // event pairs bracket k_scan (+ moments merge when it is a launch), k_wind, k_t0/k_gz, k_thc2/k_thc, (unused)
+    // event pairs bracket k_scan (+ moments merge when it is a launch), k_wind, k_t0, k_thc2, (unused)
     static const int first[SB_PROF_KERNELS] = {0, 2, 4, 5, 6}, last[SB_PROF_KERNELS] = {1, 3, 5, 6, 7};
     double sum[SB_PROF_KERNELS] = {0, 0, 0, 0, 0};
     for (int i = 0; i < c->prof_calls; ++i)

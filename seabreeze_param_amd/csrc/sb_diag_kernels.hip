@@ -282,56 +282,6 @@ __global__ __launch_bounds__(256) void k_t0(DiagJob<T> job) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_gz: gz = (gmma*z)*sigmoid(sigma), the static part of t0 = theta - gz (ref: generic/
-// sea_breeze_diag.f90:166-167), for the host-model flavour.  Only the k_thc tiles within
-// the LDS halo of an active tile are filled (about 4 in 10): one workgroup per tile checks
-// the flags of its neighbourhood first.  With ghost cells (multi-GPU bands) every cell is
-// filled.  k_thc then stages theta - gz, with no exp in its (issue-bound) staging loop.
-// ------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T sb_gz(T z, T sigma, T sd, T r) {
-    const T gzm = T(-0.0060956) * z;
-    if (z == T(0)) return gzm;                   // a signed zero whatever the sigmoid: skip the exp
-    return gzm * (T(1) / (T(1) + exp(-sd * (sigma - r))));
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_gz(DiagJob<T> job, int dxt, int dyt) {
-    const Geo g = job.g;
-    const int tx = blockIdx.x, ty = blockIdx.y, TY = job.thc_ty;
-    const T sd = job.stats[0], r = job.stats[1];
-    if (g.h > 0) {
-        // ghost-celled band: plain sweep of the whole (nxh, nyh) frame, 64 x TY cells per workgroup
-        for (int i = threadIdx.x; i < 64 * TY; i += 256) {
-            const int X = tx * 64 + (i & 63), Y = ty * TY + (i >> 6);
-            if (X < g.nxh && Y < g.nyh) {
-                const size_t idx = (size_t)Y * g.nxh + X;
-                job.t0[idx] = sb_gz<T>(job.z[idx], job.sigma[idx], sd, r);
-            }
-        }
-        return;
-    }
-    // is any tile within (dxt, dyt) tiles of this one active?  (longitude wraps, latitude does not)
-    int any = 0;
-    const int nnb = (2 * dxt + 1) * (2 * dyt + 1);
-    for (int i = threadIdx.x; i < nnb; i += 256) {
-        const int ddx = i % (2 * dxt + 1) - dxt, ddy = i / (2 * dxt + 1) - dyt;
-        const int yy = ty + ddy;
-        int xx = (tx + ddx) % job.thc_ntx;
-        if (xx < 0) xx += job.thc_ntx;
-        if (yy >= 0 && yy < job.thc_nty && job.tile_nnmax[yy * job.thc_ntx + xx] != 0) any = 1;
-    }
-    if (!__syncthreads_or(any)) return;
-    for (int i = threadIdx.x; i < 64 * TY; i += 256) {
-        const int x = tx * 64 + (i & 63), y = ty * TY + (i >> 6);
-        if (x < g.nx && y < g.ny) {
-            const size_t idx = (size_t)y * g.nx + x;
-            job.t0[idx] = sb_gz<T>(job.z[idx], job.sigma[idx], sd, r);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // Dense band-cell enumeration inside a workgroup: the workgroup covers 256 consecutive
 // longitudes of one latitude row; the band cells among them are compacted (ballot +
 // popcount prefix) so that thread i owns the i-th band cell.  Waves are full however
@@ -513,13 +463,10 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     hipStream_t st = lc.stream;
     hipEvent_t *ev = lc.prof;
     static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 8;   // tuning knob (diagnostic)
-    static const bool old_thc = getenv("SB_OLD_THC") != nullptr;                  // k_gz + k_thc instead of k_thc2 (diagnostic)
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
-    // the fused second half (k_thc2) exists for LDS halos of 8, 16 and 32; 24 keeps k_gz + k_thc
-    const bool thc2 = (H <= 16 || H == 32) && !old_thc;
     // k_thc2 merges k_scan's moments itself; the f2py flavour needs the scalars earlier, for k_t0
-    const bool merge_in_thc2 = thc2 && job.t0_fly && !gathered;
+    const bool merge_in_thc2 = job.t0_fly && !gathered;
     hipError_t e = hipSuccess;
     const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
     int nblk = (int)((nseg + 79) / 80);                          // 16 waves x 5 segments per trip
@@ -578,21 +525,12 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
                                          (T *)lc.stats);
         if (ev) (void)hipEventRecord(ev[4], st);
-        // k_t0 (f2py flavour: the t0 plane is an output) / k_gz (host-model flavour on the k_thc path only)
+        // k_t0 (f2py flavour: the t0 plane is an output)
         if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-        else if (!thc2) {
-            const int TY = job.thc_ty;
-            // tiles to look at around a tile: the halo H in tile units; one more column at the
-            // longitude seam when the last tile column is narrower than a tile
-            const int dyt = (H + TY - 1) / TY, dxt = 1 + ((g.nx & 63) ? 1 : 0);
-            const dim3 gg = g.h > 0 ? dim3((g.nxh + 63) / 64, (g.nyh + TY - 1) / TY) : dim3(job.thc_ntx, (g.ny + TY - 1) / TY);
-            hipLaunchKernelGGL(k_gz<T>, gg, dim3(256), 0, st, job, dxt, dyt);
-        }
         if (ev) (void)hipEventRecord(ev[5], st);
         // contrast, thresholds, state update
-        if (thc2) e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
-                                        (T *)lc.stats, st);
-        else e = sb_launch_thc<T>(job, H, lc.ncu, true, st);
+        e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
+                              (T *)lc.stats, st);
         if (e != hipSuccess) return e;
         if (ev) (void)hipEventRecord(ev[6], st);
         if (ev) (void)hipEventRecord(ev[7], st);

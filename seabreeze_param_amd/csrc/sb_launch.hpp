@@ -6,7 +6,7 @@
 #define SB_MAX_LDS_HALO 32          // largest LDS halo a contrast kernel is instantiated for (k_thc2; 24: k_thc)
 #define SB_DIST_TY 4                 // rows per k_dist tile
 #define SB_PROF_EVENTS 8            // events one profiled diag call records
-#define SB_PROF_KERNELS 5           // k_scan, k_wind, k_t0/k_gz, k_thc, k_final_tiles
+#define SB_PROF_KERNELS 5           // k_scan, k_wind, k_t0, k_thc2, (unused)
 
 // Everything of the context a diag launch needs besides the job itself.
 struct SbLaunchCtx {
@@ -18,7 +18,7 @@ struct SbLaunchCtx {
     int ngathered;
     int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
     int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
-                                    // bit 1: statistics merge, k_t0/k_gz, k_thc.  3 = the whole call
+                                    // bit 1: statistics merge, k_t0, k_thc2.  3 = the whole call
 };
 
 template <typename T>
@@ -28,10 +28,7 @@ template <typename T>
 hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats, hipStream_t st);
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
-int sb_thc_tile_rows(int H);
-void sb_thc_tile_shape(int H, bool thc2, int nx, int rows, int ncu, int *tx, int *ty);         // tile size of the contrast kernel that will run                                         // k_thc tiles are 64 x this many cells
-template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse_final, hipStream_t st);
+void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);         // tile size of the contrast kernel that will run                                         // k_thc tiles are 64 x this many cells
 // the fused second half (H <= 16): partials/nparts: k_scan's moments to merge (0: read job.stats)
 template <typename T>
 hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *partials, int nparts, T *stats_out,

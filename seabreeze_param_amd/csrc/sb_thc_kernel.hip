@@ -3,17 +3,16 @@
 // python_wrapper/seabreezediag/seabreeze_diag_python.f90:187-221
 //
 // The reference re-sums a (2nn+1)^2 window from scratch at every radius nn until it holds
-// both classes; only the last square matters.  Here a tile of 64 x TY cells plus a halo of
-// H cells is staged once into LDS as three summed-area tables (all cells, land-side
-// cells, land-side count), after which any square costs four LDS reads per table and the
+// both classes; only the last square matters.  Here a tile of 32 x TY cells plus a halo of
+// H cells is held in LDS as three summed-area tables (all cells, land-side cells,
+// land-side count), after which any square costs four LDS reads per table and the
 // smallest valid radius is found by bisection (the "both classes present" predicate is
 // monotone in nn).  Sums are taken about a per-tile offset c0, which cancels exactly in
 // the difference of the two means and keeps the fp64 prefix sums small.
 //
-// One persistent 1024-thread workgroup per CU (the tables take 113 KB of the 160 KB LDS):
-// every workgroup compacts the tile flags k_prep raised into the ordered list of active
-// tiles and takes entries blockIdx, blockIdx + gridDim, ... -- tiles that do not touch the
-// coastal band (about 3 in 4) cost nothing, and the active ones are dealt out evenly.
+// One persistent 512-thread workgroup per CU (k_thc2, below): tiles that do not touch the
+// coastal band (about 3 in 4) cost nothing, the others are dealt out from the compacted list
+// of tile flags k_scan raised.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"
 
@@ -24,7 +23,6 @@
 #define SB_STAMP(i) do { } while (0)
 #endif
 
-#define THC_NT 1024
 #define THC_MAXMINE 256          // active tiles one workgroup can own
 // k_thc2 tiles are 32 longitudes x 64 latitudes: with the halo a staged row is exactly one 64-lane
 // chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
@@ -32,6 +30,7 @@
 #define THC2_TY 64
 #define THC2_TYS 32               // small grids (a band of a multi-GPU run, N512): half-height tiles, so that more
                                   // of the one-workgroup-per-CU grid has a tile and each tile is shorter
+#define THC2_TY24 32              // tile rows with a halo of 24 (81 x 81 table entries)
 #define THC2_TY32 16              // tile rows with a halo of 32: 81 x 97 table entries are what 160 KB of LDS hold
 #ifndef THC2_NT
 #define THC2_NT 512               // k_thc2: 8 waves per CU, so that a thread may hold 256 registers
@@ -177,7 +176,7 @@ __device__ __forceinline__ int thc_pos_to_tile(int pos, int c, int incl, const u
 // ballot words.  A chunk is K * NT = 64 * 64 tiles whose flags are all loaded at once; `pre`: the flags of
 // chunk 0 already loaded by thc_list_preload (issued early, so that other work hides the round trip), or
 // nullptr.  A grid of at most one chunk (4096 tiles) needs two barriers and no second look at the flags.
-template <int NT = THC_NT>
+template <int NT>
 __device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int ntiles, int *s_mine, int *s_wcnt,
                                               unsigned long long *s_bm, const int *pre = nullptr) {
     constexpr int NWV = NT / SB_WAVE, K = SB_WAVE / NWV, NE = K * NWV;   // K flag loads in flight per thread
@@ -247,288 +246,6 @@ __device__ __forceinline__ int thc_build_list(const int *__restrict__ flags, int
     }
     return nmine;
 }
-
-template <typename T, int TY, int H, bool FLY, bool FUSE>
-__global__ __launch_bounds__(THC_NT) void k_thc(DiagJob<T> job) {
-    constexpr int TX = 64, NT = THC_NT;
-    constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
-    constexpr int CPT = TX * TY / NT;            // cells per thread in the search phase
-    constexpr int NWV = NT / SB_WAVE;
-    constexpr int RPW = (HT + NWV - 1) / NWV;    // LDS rows staged per wave
-    constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;   // 64-column chunks per LDS row
-    static_assert((TX * TY) % NT == 0 && CPT >= 1, "tile/thread shape");
-    static_assert((size_t)W * HT < 65536, "u16 count table");
-    static_assert(HT % 16 == 0 && W % 16 == 0, "the scans run in batches of 16");
-    __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
-    __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
-    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
-    __shared__ int s_mine[THC_MAXMINE];
-    __shared__ int s_wcnt[SB_WAVE];
-    __shared__ int s_nn;
-
-    const Geo g = job.g;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ntx = job.thc_ntx, ntiles = job.thc_ntx * job.thc_nty;
-
-    __shared__ unsigned long long s_bmw[SB_WAVE];
-    int nmine = thc_build_list(job.tile_nnmax, ntiles, s_mine, s_wcnt, s_bmw);
-    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
-    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
-    const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
-
-    for (int mi = 0; mi < nmine; ++mi) {
-        const int tile = s_mine[mi];
-        const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
-        SB_STAMP(0);
-        if (tid == 0) s_nn = 1;
-
-        // ---- issue every global load of the tile before touching any result -------------
-        // my search cells' band bits, the tile offset c0, and RPW x NCH staged values/words
-        const int lx = tid % TX, ly0 = tid / TX;
-        uint64_t bw[CPT], cw[CPT];
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int x = x0 + lx, y = y0 + ly0 + q * (NT / TX);
-            bw[q] = 0;
-            cw[q] = 0;
-            if (x < g.nx && y < g.rows) {
-                const size_t wi = (size_t)(y + g.h) * g.nw + ((x + g.h) >> 6);
-                bw[q] = job.bandbits[wi];
-                cw[q] = job.clsbits[wi];
-            }
-        }
-        // t0 of one cell: read from the workspace (f2py flavour, where the t0 plane is an output),
-        // or formed here as theta - gz with gz = (gmma*z)*sigmoid(sigma) (ref: generic/
-        // sea_breeze_diag.f90:167) left by k_gz in the same workspace for the tiles that need it
-        int X, Y;
-        sb_map_cell(g, x0, y0, X, Y);
-        const unsigned unxh = (unsigned)g.nxh;
-        const unsigned i00 = (unsigned)Y * unxh + (unsigned)X;
-        T c_th = T(0), c_gz = T(0), c_t0 = T(0);
-        if constexpr (FLY) { c_th = job.theta[i00]; c_gz = job.t0[i00]; }
-        else c_t0 = job.t0[i00];
-        // array column of each of my NCH chunks (-1: no such cell): the longitude map is the
-        // same for every row this thread stages, so it is evaluated once per tile
-        int xcol[NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int c = ch * SB_WAVE + lane;
-            const int xs = x0 - H + c;
-            bool ok = c < W;
-            int Xc = 0;
-            if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
-            else if (fastx) {
-                if (g.bnd == BND_WRAPPER) {
-                    int m = xs + 1;
-                    m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
-                    Xc = (m < 1 ? 1 : m) - 1;
-                } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
-            } else {
-                int Yd;
-                sb_map_cell(g, xs, y0, Xc, Yd);
-            }
-            xcol[ch] = ok ? Xc : -1;
-        }
-        // every global load of the tile is issued before any result is used
-        T dv[RPW * NCH], zv[FLY ? RPW * NCH : 1];
-        uint64_t lw[RPW * NCH];
-        unsigned rowmask = 0;
-#pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) {
-            const int r = wv + ri * NWV;
-            const int ys = y0 - H + r;
-            int Yr;
-            bool rowok = r < HT;
-            if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = rowok && (Yr >= 0 && Yr < g.nyh); }
-            else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-            rowmask |= (rowok ? 1u : 0u) << ri;
-            const unsigned rowbase = (unsigned)Yr * unxh, wordbase = (unsigned)Yr * (unsigned)g.nw;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int k = ri * NCH + ch;
-                dv[k] = T(0);
-                lw[k] = 0;
-                if constexpr (FLY) zv[k] = T(0);
-                if (rowok && xcol[ch] >= 0) {
-                    const unsigned ii = rowbase + (unsigned)xcol[ch];
-                    if constexpr (FLY) { dv[k] = job.theta[ii]; zv[k] = job.t0[ii]; }
-                    else dv[k] = job.t0[ii];
-                    lw[k] = job.clsbits[wordbase + ((unsigned)xcol[ch] >> 6)];
-                }
-            }
-        }
-        if constexpr (FLY) c_t0 = c_th - c_gz;
-        const double c0 = (double)c_t0;
-        unsigned mine = 0;
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) mine |= (unsigned)((bw[q] >> ((x0 + lx + g.h) & 63)) & 1ull) << q;
-        // ---- into LDS; the land-side count is prefixed along the row on the way in with a
-        // ballot + popcount, so only the two fp64 tables need a longitude scan ----------------
-#pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) {
-            const int r = wv + ri * NWV;
-            const bool rowok = (rowmask >> ri) & 1u;
-            unsigned carryC = 0;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int k = ri * NCH + ch;
-                const int c = ch * SB_WAVE + lane;
-                const bool ok = rowok && xcol[ch] >= 0;
-                const int land = ok ? (int)((lw[k] >> (xcol[ch] & 63)) & 1ull) : 0;
-                T t0v = dv[k];
-                if constexpr (FLY) t0v = dv[k] - zv[k];
-                const double d = ok ? (double)t0v - c0 : 0.0;
-                const uint64_t lm = __ballot(land);
-                const unsigned cn = carryC + (unsigned)__popcll(lm & (~0ull >> (63 - lane)));
-                carryC += (unsigned)__popcll(lm);
-                if (r < HT && c < W) {
-                    const int o = (r + 1) * P + c + 1;
-                    sA[o] = d;
-                    sL[o] = land ? d : 0.0;
-                    sC[o] = (unsigned short)cn;
-                }
-            }
-        }
-        __syncthreads();
-        SB_STAMP(1);
-        // ---- prefix along longitude: one task per (fp64 table, row), batches of 16 ----------
-        for (int task = tid; task < 2 * HT; task += NT) {
-            const int a = task / HT, r = task - a * HT + 1;
-            double *row = (a == 0 ? sA : sL) + r * P;
-            double s = 0.0;
-            for (int cb = 1; cb <= W; cb += 16) {
-                double v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = row[cb + i];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { s += v[i]; v[i] = s; }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) row[cb + i] = v[i];
-            }
-        }
-        __syncthreads();
-        SB_STAMP(2);
-        // the state / wind loads of the final update: issued now, they land under the scan
-        SbCellState<T> cst[CPT];
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            cst[q] = SbCellState<T>{T(0), T(0), T(0), T(0)};
-            if (FUSE && ((mine >> q) & 1u))
-                cst[q] = sb_trigger_load<T>(job, (size_t)(y0 + ly0 + q * (NT / TX)) * g.nx + (x0 + lx));
-        }
-        // ---- prefix along latitude: one task per (table, column), batches of 16 rows ------
-        for (int task = tid; task < 3 * W; task += NT) {
-            const int a = task / W, c = task - a * W + 1;
-            if (a < 2) {
-                double *tab = (a == 0 ? sA : sL) + c;
-                double s = 0.0;
-                for (int rb = 1; rb <= HT; rb += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = tab[(rb + i) * P];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { s += v[i]; v[i] = s; }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) tab[(rb + i) * P] = v[i];
-                }
-            } else {
-                unsigned short *tab = sC + c;
-                unsigned s = 0;
-                for (int rb = 1; rb <= HT; rb += 16) {
-                    unsigned v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = tab[(rb + i) * P];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { s += v[i]; v[i] = s; }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) tab[(rb + i) * P] = (unsigned short)v[i];
-                }
-            }
-        }
-        __syncthreads();
-        SB_STAMP(3);
-
-        // ---- smallest radius whose square holds both classes: bisection, O(1) per probe ---
-        int cxq[CPT], cyq[CPT], lo[CPT], hi[CPT], nlq[CPT];
-        bool fnd[CPT];
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int ly = ly0 + q * (NT / TX);
-            const int x = x0 + lx, y = y0 + ly;
-            cxq[q] = lx + H;
-            cyq[q] = ly + H;
-            int lim = H;
-            if (g.bnd == BND_HALO)
-                lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
-            lo[q] = 1;
-            hi[q] = lim;
-            fnd[q] = false;
-            nlq[q] = 0;
-            if ((mine >> q) & 1u) {
-                if (lim >= 1) {
-                    const int r0 = (cyq[q] - lim) * P, r1 = (cyq[q] + lim + 1) * P;
-                    const int a0 = cxq[q] - lim, a1 = cxq[q] + lim + 1;
-                    const int nl = (int)sC[r1 + a1] - (int)sC[r0 + a1] - (int)sC[r1 + a0] + (int)sC[r0 + a0];
-                    fnd[q] = nl > 0 && nl < (2 * lim + 1) * (2 * lim + 1);
-                    nlq[q] = nl;
-                }
-            }
-            if (!fnd[q]) lo[q] = hi[q];          // nothing to bisect
-        }
-        constexpr int ITER = (H <= 2 ? 1 : H <= 4 ? 2 : H <= 8 ? 3 : H <= 16 ? 4 : 5);
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                if (lo[q] < hi[q]) {
-                    const int mid = (lo[q] + hi[q]) >> 1;
-                    const int r0 = (cyq[q] - mid) * P, r1 = (cyq[q] + mid + 1) * P;
-                    const int a0 = cxq[q] - mid, a1 = cxq[q] + mid + 1;
-                    const int nl = (int)sC[r1 + a1] - (int)sC[r0 + a1] - (int)sC[r1 + a0] + (int)sC[r0 + a0];
-                    if (nl > 0 && nl < (2 * mid + 1) * (2 * mid + 1)) { hi[q] = mid; nlq[q] = nl; }
-                    else lo[q] = mid + 1;
-                }
-            }
-        }
-        int nnmax = 0;
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            if (!((mine >> q) & 1u)) continue;
-            const int ly = ly0 + q * (NT / TX);
-            const int x = x0 + lx, y = y0 + ly;
-            int nn = hi[q];
-            T contrast;
-            if (fnd[q]) {
-                const int r0 = (cyq[q] - nn) * P, r1 = (cyq[q] + nn + 1) * P;
-                const int a0 = cxq[q] - nn, a1 = cxq[q] + nn + 1;
-                const int area = (2 * nn + 1) * (2 * nn + 1);
-                const double RL = (sL[r1 + a1] - sL[r0 + a1]) - (sL[r1 + a0] - sL[r0 + a0]);
-                const double RA = (sA[r1 + a1] - sA[r0 + a1]) - (sA[r1 + a0] - sA[r0 + a0]);
-                contrast = (T)(RL / (double)nlq[q] - (RA - RL) / (double)(area - nlq[q]));
-            } else {
-                int cap = g.nx + g.ny;
-                if (g.bnd == BND_HALO)
-                    cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
-                bool one_class;
-                contrast = contrast_global(job, x, y, cap, job.t0_fly ? job.stats[0] : T(0), job.t0_fly ? job.stats[1] : T(0), nn, one_class);
-                atomicAdd(&job.counters[0], 1);
-                if (one_class) atomicAdd(&job.counters[1], 1);
-            }
-            nnmax = max(nnmax, nn);
-            const T mul = ((cw[q] >> ((x + g.h) & 63)) & 1ull) ? T(1) : T(-1);        // ref :182-186
-            if constexpr (FUSE) sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);  // ref :216, :235-266
-            else job.thc[(size_t)y * g.nx + x] = mul * contrast;       // k_final_tiles applies :235-266
-        }
-        // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nnmax = max(nnmax, __shfl_xor(nnmax, off));
-        if (lane == 0 && nnmax > 1) atomicMax(&s_nn, nnmax);
-        __syncthreads();                         // also fences the tables before the next tile
-        if (tid == 0) job.tile_nnmax[tile] = s_nn;
-        SB_STAMP(5);
-    }
-}
-
 
 // ====================================================================================
 // k_thc2: the whole second half of a diag call in one persistent launch (halo H <= 16):
@@ -1132,22 +849,15 @@ hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *
     if (H <= 8) launch_thc2<T, THC2_TX, THC2_TY, 8>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 16 && job.thc_ty == THC2_TYS) launch_thc2<T, THC2_TX, THC2_TYS, 16>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 16) launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
+    else if (H <= 24) launch_thc2<T, THC2_TX, THC2_TY24, 24>(job, nblocks, partials, nparts, stats_out, st);
     else launch_thc2<T, THC2_TX, THC2_TY32, 32>(job, nblocks, partials, nparts, stats_out, st);   // H == 32
     return hipGetLastError();
 }
 template hipError_t sb_launch_thc2<float>(const DiagJob<float> &, int, int, const Moments *, int, float *, hipStream_t);
 template hipError_t sb_launch_thc2<double>(const DiagJob<double> &, int, int, const Moments *, int, double *, hipStream_t);
 
-template <typename T, int TY, int H>
-static void launch_thc(const DiagJob<T> &job, int nblocks, bool fuse, hipStream_t st) {
-    (void)fuse;
-    if (job.t0_fly) hipLaunchKernelGGL((k_thc<T, TY, H, true, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
-    else hipLaunchKernelGGL((k_thc<T, TY, H, false, true>), dim3(nblocks), dim3(THC_NT), 0, st, job);
-}
-
-int sb_thc_tile_rows(int H) { return H <= 16 ? 32 : 16; }
-void sb_thc_tile_shape(int H, bool thc2, int nx, int rows, int ncu, int *tx, int *ty) {
-    if (thc2 && H <= 16) {
+void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty) {
+    if (H <= 16) {
         *tx = THC2_TX;
         *ty = THC2_TY;
         // about a quarter of the tiles touch the coastal band: while even twice the full-height tile count
@@ -1155,21 +865,7 @@ void sb_thc_tile_shape(int H, bool thc2, int nx, int rows, int ncu, int *tx, int
         const long long full = (long long)((nx + THC2_TX - 1) / THC2_TX) * ((rows + THC2_TY - 1) / THC2_TY);
         if (H > 8 && full <= 2LL * ncu) *ty = THC2_TYS;
     }
-    else if (thc2 && H == 32) { *tx = THC2_TX; *ty = THC2_TY32; }
-    else { *tx = 64; *ty = sb_thc_tile_rows(H); }
+    else if (H <= 24) { *tx = THC2_TX; *ty = THC2_TY24; }
+    else { *tx = THC2_TX; *ty = THC2_TY32; }
 }
 
-template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, bool fuse, hipStream_t st) {
-    // one workgroup per CU; more only if a workgroup could own more tiles than its list holds
-    const int ntiles = job.thc_ntx * job.thc_nty;
-    int nblocks = ncu;
-    while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
-    if (H <= 8) launch_thc<T, 32, 8>(job, nblocks, fuse, st);
-    else if (H <= 16) launch_thc<T, 32, 16>(job, nblocks, fuse, st);
-    else launch_thc<T, 16, 24>(job, nblocks, fuse, st);
-    return hipGetLastError();
-}
-
-template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, bool, hipStream_t);
-template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, bool, hipStream_t);

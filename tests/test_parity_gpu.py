@@ -324,8 +324,7 @@ def test_halo_32_holds_radii_up_to_32_in_lds(hipctx, oracles):
 
 
 def test_wide_halo_path_matches_oracle(hipctx, oracles):
-    """A radius hint above 16 selects the LDS halo of 24 cells, which runs the separate
-    k_moments_final + k_gz + k_thc kernels (64-wide tiles) instead of k_thc2: same numbers."""
+    """A radius hint of 17..24 selects the LDS halo of 24 cells (k_thc2 with 32 x 32 tiles): same numbers."""
     nx, ny, nz = 256, 192, 3
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)

@@ -35,10 +35,7 @@ s = np.frombuffer(buf, dtype=np.int64)[: n.value * NS].reshape(n.value, NS)
 LAST = 5
 active = s[:, LAST] != 0
 print(f"tiles {n.value}, active {int(active.sum())}")
-if "SB_OLD_THC" in __import__("os").environ:
-    names, idx = ["loads->LDS", "lon scan", "lat scan", "search+store"], [0, 1, 2, 3, 5]
-else:       # k_thc2
-    names, idx = ["T0 compact", "T1 regs->LDS", "T2 band prefix", "T3 lon prefix", "T4 search"], [0, 1, 2, 3, 4, 5]
+names, idx = ["T0 compact", "T1 regs->LDS", "T2 band prefix", "T3 lon prefix", "T4 search"], [0, 1, 2, 3, 4, 5]
 a = s[active]
 for i, nm in enumerate(names):
     d = a[:, idx[i + 1]] - a[:, idx[i]]
