@@ -55,7 +55,7 @@ struct sb_ctx {
     int prof_calls = 0, prof_max = 0;
     // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
     hipStream_t aux_stream = nullptr;   // communication of a band step runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mom = nullptr;
     DevBuf band_mom;                    // [5 own moments | 5 x nranks gathered]
     void *rccl_lib = nullptr;
     void *comm = nullptr;
@@ -247,14 +247,19 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
+    if (!c->ev_mom) HIPCHK(c, hipEventCreateWithFlags(&c->ev_mom, hipEventDisableTiming));
     if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
     double *mine = (double *)c->band_mom.p, *gath = mine + 5;
-    // fork: everything that talks to the neighbours goes to the second stream
+    // fork: everything that talks to the neighbours goes to the second stream.  The ghost rows of theta
+    // need nothing from this step, so they travel first, while this band's sigma moments are formed on
+    // the caller's stream; the all-gather follows them (every rank issues the two in this order).
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream))) return rc;
-    if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
     if ((rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream))) return rc;
+    if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)st))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_mom, st));
+    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0));
+    if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
     // phase 1 on the caller's stream meanwhile
     const Moments *saved_g = c->gathered;
@@ -607,6 +612,7 @@ int sb_destroy(sb_ctx *c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_mom) (void)hipEventDestroy(c->ev_mom);
     if (c->band_mom.p) (void)hipFree(c->band_mom.p);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
