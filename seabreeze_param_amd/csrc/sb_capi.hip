@@ -50,6 +50,8 @@ struct sb_ctx {
     bool have_last = false;
     // optional per-kernel HIP-event timing (sb_profile_begin / sb_profile_end)
     const Moments *gathered = nullptr;   // device array of per-band sigma moments (multi-GPU), or null
+    Moments *band_moments_out = nullptr; // set by the band step for its phase-1 call: where k_scan's moments go
+    hipEvent_t band_moments_event = nullptr;
     int ngathered = 0;
     std::vector<hipEvent_t> prof_ev;
     int prof_calls = 0, prof_max = 0;
@@ -176,6 +178,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if (phases == 3 && c->prof_calls < c->prof_max) lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
+    lc.moments_out = (phases & 1) ? c->band_moments_out : nullptr;
+    lc.moments_event = (phases & 1) ? c->band_moments_event : nullptr;
     lc.phases = phases;
     HIPCHK(c, sb_launch_diag<T>(job, H, lc));
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
@@ -256,18 +260,27 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
     if ((rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream))) return rc;
-    if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)st))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_mom, st));
-    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0));
-    if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
-    // phase 1 on the caller's stream meanwhile
+    // phase 1 on the caller's stream meanwhile: k_scan also forms this band's sigma moments, a one-workgroup
+    // merge publishes them (ev_mom), k_wind follows; the all-gather waits for ev_mom on the second stream
     const Moments *saved_g = c->gathered;
     const int saved_n = c->ngathered;
     c->gathered = (const Moments *)gath;
     c->ngathered = c->nranks;
+    c->band_moments_out = (Moments *)mine;
+    c->band_moments_event = c->ev_mom;
     rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
                                thc, sb_con, tun, (void *)st, 1);
+    c->band_moments_out = nullptr;
+    c->band_moments_event = nullptr;
+    if (!rc) {
+        hipError_t e = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);
+        if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
+    }
+    if (!rc) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
+    if (!rc) {
+        hipError_t e = hipEventRecord(c->ev_join, c->aux_stream);
+        if (e != hipSuccess) rc = hipfail(c, e, "hipEventRecord");
+    }
     if (!rc) {
         hipError_t e = hipStreamWaitEvent(st, c->ev_join, 0);
         if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");

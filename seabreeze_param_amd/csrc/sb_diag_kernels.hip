@@ -505,7 +505,14 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     if (ph1) {
         // k_scan (+ merge of the statistics when they are this domain's own and k_thc2 does not do it)
         if (ev) (void)hipEventRecord(ev[0], st);
-        launch_scan<T>(job, nblk, lc.partials, !gathered, st);
+        // a band step takes this band's own sigma moments from the same pass (lc.moments_out), publishes
+        // them for the all-gather and signals the communication stream
+        launch_scan<T>(job, nblk, lc.partials, !gathered || lc.moments_out != nullptr, st);
+        if (gathered && lc.moments_out) {
+            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
+                               lc.moments_out);
+            if (lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
+        }
         if (!gathered && !merge_in_thc2)
             hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
                                (Moments *)nullptr);
@@ -522,15 +529,19 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
-        if (gathered) hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered,
-                                         (T *)lc.stats);
+        // the bands' moments: merged by k_thc2 itself (host-model flavour, up to 64 bands: the same tree as
+        // k_merge_moments) or by a launch of their own (the f2py flavour's k_t0 needs the scalars first)
+        const bool gath_in_thc2 = gathered && job.t0_fly && lc.ngathered <= SB_WAVE;
+        if (gathered && !gath_in_thc2)
+            hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered, (T *)lc.stats);
         if (ev) (void)hipEventRecord(ev[4], st);
         // k_t0 (f2py flavour: the t0 plane is an output)
         if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
         if (ev) (void)hipEventRecord(ev[5], st);
         // contrast, thresholds, state update
-        e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
-                              (T *)lc.stats, st);
+        const Moments *mp = merge_in_thc2 ? lc.partials : gath_in_thc2 ? lc.gathered : nullptr;
+        const int mn = merge_in_thc2 ? nblk : gath_in_thc2 ? lc.ngathered : 0;
+        e = sb_launch_thc2<T>(job, H, lc.ncu, mp, mn, (T *)lc.stats, st);
         if (e != hipSuccess) return e;
         if (ev) (void)hipEventRecord(ev[6], st);
         if (ev) (void)hipEventRecord(ev[7], st);

@@ -16,6 +16,8 @@ struct SbLaunchCtx {
     void *stats;                    // sigmoid scalars (4 x T)
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
+    Moments *moments_out;           // band step: k_scan's own moments go here (k_moments_final) ...
+    hipEvent_t moments_event;       // ... and this event is recorded behind them, or nullptr
     int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
     int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics merge, k_t0, k_thc2.  3 = the whole call
