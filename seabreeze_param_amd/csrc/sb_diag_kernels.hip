@@ -343,8 +343,17 @@ __device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ ban
 // no band cell, and the launch of their waves is a measurable share of the kernel (14 us for the
 // empty grid at CPW = 1 on the 2560 x 1920 grid), so fewer, wider workgroups are launched.
 // ------------------------------------------------------------------------------------
+#ifndef SB_WIND_MINW
+#define SB_WIND_MINW 6               // minimum waves per SIMD asked of the compiler for k_wind: 6 workgroups per CU instead of 5
+                                     // (78 instead of 93 registers, none spilled; 8 would spill: the fp64 atan2 and update set the count)
+#endif
+#if SB_WIND_MINW > 0
+#define SB_WIND_BOUNDS __launch_bounds__(ROW_NT, SB_WIND_MINW)
+#else
+#define SB_WIND_BOUNDS __launch_bounds__(ROW_NT)
+#endif
 template <typename T, int UN, bool NTL, int CPW = 1>
-__global__ __launch_bounds__(ROW_NT) void k_wind(DiagJob<T> job, int ystride, int early) {
+__global__ SB_WIND_BOUNDS void k_wind(DiagJob<T> job, int ystride, int early) {
     __shared__ unsigned short s_x[ROW_NT * CPW];
     __shared__ int s_wcnt[ROW_NT / SB_WAVE * CPW];
     const Geo g = job.g;
