@@ -344,9 +344,8 @@ __device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ ban
 // empty grid at CPW = 1 on the 2560 x 1920 grid), so fewer, wider workgroups are launched.
 // ------------------------------------------------------------------------------------
 #ifndef SB_WIND_MINW
-#define SB_WIND_MINW 6               // minimum waves per SIMD asked of the compiler for k_wind: 6 workgroups per CU instead of 5
-                                     // (78 instead of 93 registers, none spilled; 8 would spill: the fp64 atan2 and update set the count)
-#endif
+#define SB_WIND_MINW 8               // waves per SIMD asked of the compiler for k_wind: 30 registers and 61 scalar
+#endif                               // registers per wave, so that eight 256-thread workgroups fit a CU
 #if SB_WIND_MINW > 0
 #define SB_WIND_BOUNDS __launch_bounds__(ROW_NT, SB_WIND_MINW)
 #else
@@ -381,7 +380,10 @@ __global__ SB_WIND_BOUNDS void k_wind(DiagJob<T> job, int ystride, int early) {
     if (early == 2) return;                                      // diagnostic: cost of the empty grid
     const size_t pl = (size_t)g.nx * g.ny;
     const int nz = job.nz;
-    for (int i = threadIdx.x; i < total; i += ROW_NT) {
+    // one band cell per thread when the workgroup covers 256 longitudes: no loop.  With a loop the compiler
+    // keeps the constants of the fp64 atan2 / update below in registers across it: 93 registers per lane
+    // and 5 workgroups per CU instead of 8, which cost the kernel 5-10 us
+    for (int i = threadIdx.x; i < total; i += (CPW == 1 ? (1 << 30) : ROW_NT)) {
         const int x = blockIdx.x * ROW_NT * CPW + s_x[i];
         const size_t o = (size_t)y * g.nx + x;
         // the final update's inputs: issued ahead of the column walk
@@ -499,12 +501,9 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[7], st); (void)hipEventRecord(ev[2], st); }
         static const int ystr = getenv("SB_WIND_YSTRIDE") ? atoi(getenv("SB_WIND_YSTRIDE")) : 1;   // tuning knob (diagnostic)
         static const int early = getenv("SB_WIND_EARLY") ? atoi(getenv("SB_WIND_EARLY")) : 0;       // tuning knob (diagnostic)
-        static const int cpw = getenv("SB_WIND_CPW") ? atoi(getenv("SB_WIND_CPW")) : 1;           // tuning knob (diagnostic)
         const int gy = ystr > 1 ? ystr * ((g.rows + ystr - 1) / ystr) : g.rows;
         const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, gy), wb(ROW_NT);
-        if (cpw == 2) hipLaunchKernelGGL((k_wind<T, 8, true, 2>), dim3((g.nx + 2 * ROW_NT - 1) / (2 * ROW_NT), gy), wb, 0, st, job, ystr, early);
-        else if (cpw == 4) hipLaunchKernelGGL((k_wind<T, 8, true, 4>), dim3((g.nx + 4 * ROW_NT - 1) / (4 * ROW_NT), gy), wb, 0, st, job, ystr, early);
-        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
+        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
         else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, ystr, early);
         else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, ystr, early);
         if (ev) { (void)hipEventRecord(ev[3], st); }
