@@ -388,7 +388,7 @@ __device__ __forceinline__ void thc2_issue_late(const DiagJob<T> &job, int tile,
     }
 }
 
-template <typename T, int TX, int TY, int H, bool FLY>
+template <typename T, int TX, int TY, int H, bool FLY, bool WF>     // WF: k_wind applies the update (job.wind_final)
 __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments *__restrict__ partials, int nparts,
                                                   T *__restrict__ stats_out) {
     constexpr int NT = THC2_NT, NWV = NT / SB_WAVE;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
             {   // unconditional loads; a thread without a cell reads the tile's first cell
                 const int cc = cq[q] >= 0 ? cq[q] : 0;
                 const int x = x0 + (cc & 63), y = y0 + (cc >> 6);
-                if (!job.wind_final) cst[q] = sb_trigger_load<T>(job, (size_t)y * g.nx + x);   // wave-uniform branch
+                if constexpr (!WF) cst[q] = sb_trigger_load<T>(job, (size_t)y * g.nx + x);
                 const unsigned X = (unsigned)(x + g.h);
                 ownw[q] = ((const uint32_t *)job.clsbits)[((size_t)(y + g.h) * g.nw + (X >> 6)) * 2 + ((X >> 5) & 1u)];
             }
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
             const T mul = ((ownbits >> q) & 1u) ? T(1) : T(-1);
             if (fnd) {
                 nnmax = max(nnmax, nn);
-                if (job.wind_final) job.thc[(size_t)y * g.nx + x] = mul * contrast;        // ref :216; k_wind applies :235-266
+                if constexpr (WF) job.thc[(size_t)y * g.nx + x] = mul * contrast;          // ref :216; k_wind applies :235-266
                 else sb_trigger_update<T>(job, (size_t)y * g.nx + x, mul * contrast, cst[q]);   // ref :216, :235-266
             } else if (valid) {                  // the window outgrows the tile: queue the cell
                 s_glob[atomicAdd(&s_nglob, 1)] = (unsigned short)cc;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
                 if (one_class) atomicAdd(&job.counters[1], 1);
                 nnmax = max(nnmax, nn);
                 const T mul = sb_bit(job.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
-                if (job.wind_final) job.thc[o] = mul * contrast;
+                if constexpr (WF) job.thc[o] = mul * contrast;
                 else sb_trigger_update<T>(job, o, mul * contrast, sb_trigger_load<T>(job, o));
             }
         }
@@ -834,10 +834,11 @@ __global__ __launch_bounds__(THC2_NT) void k_thc2(DiagJob<T> job, const Moments 
 template <typename T, int TX, int TY, int H>
 static void launch_thc2(const DiagJob<T> &job, int nblocks, const Moments *partials, int nparts, T *stats_out,
                         hipStream_t st) {
-    if (job.t0_fly)
-        hipLaunchKernelGGL((k_thc2<T, TX, TY, H, true>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
-    else
-        hipLaunchKernelGGL((k_thc2<T, TX, TY, H, false>), dim3(nblocks), dim3(THC2_NT), 0, st, job, partials, nparts, stats_out);
+    const dim3 gr(nblocks), bl(THC2_NT);
+    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc2<T, TX, TY, H, true, true>), gr, bl, 0, st, job, partials, nparts, stats_out);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_thc2<T, TX, TY, H, true, false>), gr, bl, 0, st, job, partials, nparts, stats_out);
+    else if (job.wind_final) hipLaunchKernelGGL((k_thc2<T, TX, TY, H, false, true>), gr, bl, 0, st, job, partials, nparts, stats_out);
+    else hipLaunchKernelGGL((k_thc2<T, TX, TY, H, false, false>), gr, bl, 0, st, job, partials, nparts, stats_out);
 }
 
 template <typename T>
