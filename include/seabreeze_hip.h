@@ -83,9 +83,9 @@ void sb_default_tunables(sb_tunables *t);
 /* Expected largest search radius of the land/sea window (selects the LDS tile halo;
    results never depend on it -- cells that need more take a global-memory path).   */
 int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
-/* Rows of the contrast kernel's LDS tiles for halos up to 16: 0 = chosen from the grid size (64, or 32
-   while the grid has too few tiles to give every compute unit one), 32 or 64 = forced.  A tuning and
-   test knob: results never depend on it.                                              */
+/* Rows of the contrast kernel's LDS tiles for halos up to 16: 0 = chosen from the grid size (48, or 32
+   while the grid has too few tiles to give every compute unit one), 32, 48 or 64 = forced.  A tuning
+   and test knob: results never depend on it.                                          */
 int  sb_set_tile_rows(sb_ctx *ctx, int rows);
 /* Counters of the last diag call: [0] band cells, [1] cells that left the LDS path,
    [2] cells whose search found only one class (result NaN; the reference loops

@@ -32,7 +32,7 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
-    int tile_rows = 0;          // 0: automatic; 32 / 64: forced k_thc2 tile height (sb_set_tile_rows)
+    int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc2 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
     // workspace (grow-only)
     DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd, coastbits;
@@ -717,7 +717,7 @@ int sb_set_search_radius_hint(sb_ctx *c, int radius) {
 
 int sb_set_tile_rows(sb_ctx *c, int rows) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    if (rows != 0 && rows != 32 && rows != 64) return fail(c, SB_ERR_ARG, "tile rows must be 0, 32 or 64");
+    if (rows != 0 && rows != 32 && rows != 48 && rows != 64) return fail(c, SB_ERR_ARG, "tile rows must be 0, 32, 48 or 64");
     c->tile_rows = rows;
     return SB_OK;
 }

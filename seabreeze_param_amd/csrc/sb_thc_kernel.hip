@@ -24,10 +24,13 @@
 #endif
 
 #define THC_MAXMINE 256          // active tiles one workgroup can own
-// k_thc2 tiles are 32 longitudes x 64 latitudes: with the halo a staged row is exactly one 64-lane
-// chunk (H = 16), so no lane of a staging load, an exp or an LDS write is padding
+// k_thc2 tiles are 32 longitudes wide: with the halo a staged row is exactly one 64-lane chunk (H = 16), so
+// no lane of a staging load, an exp or an LDS write is padding.  48 latitudes by default: on the N1280 grid
+// the coastal band touches 670 such tiles (575 of 64 rows, 1004 of 32) and tiles x staged rows is smallest
+// there -- 47 us against 50 (64 rows) and 52 (32 rows).
 #define THC2_TX 32
-#define THC2_TY 64
+#define THC2_TY 48
+#define THC2_TYL 64               // taller tiles, by sb_set_tile_rows only
 #define THC2_TYS 32               // small grids (a band of a multi-GPU run, N512): half-height tiles, so that more
                                   // of the one-workgroup-per-CU grid has a tile and each tile is shorter
 #define THC2_TY24 32              // tile rows with a halo of 24 (81 x 81 table entries)
@@ -849,6 +852,7 @@ hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *
     while ((ntiles + nblocks - 1) / nblocks + 8 > THC_MAXMINE) nblocks *= 2;
     if (H <= 8) launch_thc2<T, THC2_TX, THC2_TY, 8>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 16 && job.thc_ty == THC2_TYS) launch_thc2<T, THC2_TX, THC2_TYS, 16>(job, nblocks, partials, nparts, stats_out, st);
+    else if (H <= 16 && job.thc_ty == THC2_TYL) launch_thc2<T, THC2_TX, THC2_TYL, 16>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 16) launch_thc2<T, THC2_TX, THC2_TY, 16>(job, nblocks, partials, nparts, stats_out, st);
     else if (H <= 24) launch_thc2<T, THC2_TX, THC2_TY24, 24>(job, nblocks, partials, nparts, stats_out, st);
     else launch_thc2<T, THC2_TX, THC2_TY32, 32>(job, nblocks, partials, nparts, stats_out, st);   // H == 32
@@ -861,9 +865,9 @@ void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty) {
     if (H <= 16) {
         *tx = THC2_TX;
         *ty = THC2_TY;
-        // about a quarter of the tiles touch the coastal band: while even twice the full-height tile count
-        // would leave workgroups without a tile, use the half-height tiles (H = 16 only)
-        const long long full = (long long)((nx + THC2_TX - 1) / THC2_TX) * ((rows + THC2_TY - 1) / THC2_TY);
+        // about a quarter of the tiles touch the coastal band: while even twice the tile count would leave
+        // workgroups without a tile, use the 32-row tiles (H = 16 only)
+        const long long full = (long long)((nx + THC2_TX - 1) / THC2_TX) * ((rows + THC2_TYL - 1) / THC2_TYL);
         if (H > 8 && full <= 2LL * ncu) *ty = THC2_TYS;
     }
     else if (H <= 24) { *tx = THC2_TX; *ty = THC2_TY24; }

@@ -97,7 +97,7 @@ class Context:
         self._chk(self.lib.sb_set_search_radius_hint(self.h, C.c_int(r)), "sb_set_search_radius_hint")
 
     def set_tile_rows(self, rows: int):
-        """0: automatic, 32 / 64: force the contrast kernel's tile height (tuning / test knob)."""
+        """0: automatic, 32 / 48 / 64: force the contrast kernel's tile height (tuning / test knob)."""
         self._chk(self.lib.sb_set_tile_rows(self.h, C.c_int(rows)), "sb_set_tile_rows")
 
     def last_counters(self):

@@ -132,10 +132,10 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[64, 32], ids=["tiles32x64", "tiles32x32"])
+@pytest.fixture(params=[64, 48, 32], ids=["tiles32x64", "tiles32x48", "tiles32x32"])
 def tile_rows(request, hipctx):
-    """Both heights of the contrast kernel's LDS tiles: by default small grids get the 32-row tiles and
-    the benchmark grid the 64-row ones, so the oracle comparisons run under each."""
+    """Every height of the contrast kernel's LDS tiles: by default small grids get the 32-row tiles and
+    the benchmark grid the 48-row ones, so the oracle comparisons run under each."""
     hipctx.set_tile_rows(request.param)
     yield request.param
     hipctx.set_tile_rows(0)
