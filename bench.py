@@ -14,7 +14,10 @@ N>1 splits the grid into N latitude bands (strong scaling): per step every rank
 all-gathers its sigma moments and swaps theta halo rows with its band neighbours over
 RCCL (the reference's swap_bounds stub, generic/halo_exchange_mod.f90:12-17).
 
-Prints ONE JSON line on rank 0 with the `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 with the `roofline`, `cpu_baseline` and `parity` objects.
+`value` is nx*ny / (wall time of the K timed steps / K), as the driver's contract asks;
+`value_median` is the same from the median of per-step HIP-event times,
+taken in a second K-step pass so that no event sits between the timed launches.
 """
 from __future__ import annotations
 
@@ -33,17 +36,17 @@ from seabreeze_param_amd import hip, synth  # noqa: E402
 from seabreeze_param_amd.bands import BandRunner, split_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+REL_FLOOR = 1e-2        # parity: |a-b| / max(|b|, REL_FLOOR)
 
 
 def algorithmic_bytes(n, n_band, nz, s=8, wind_final=True):
     """B = s*[5N + (nz+7)*N_c], split per kernel."""
     return {
         "k_scan": s * (3 * n - n_band),                    # read sigma, mask; write sb_con outside the band
-        # single domain: k_wind applies the thresholds and the state update; a band step leaves that to k_thc2
+        # single domain: k_wind applies the thresholds and the state update; a band step leaves that to k_thc3
         "k_thc": s * (2 * n + (0 if wind_final else 6 * n_band)),      # theta, z in (sigma's second read is not counted)
         "k_wind": s * (nz + (8 if wind_final else 2)) * n_band,        # p column, u, v (+ ws, wd in; ws, wd, thc, sb_con out)
-        "k_gz": 0,                                         # not launched on the default path
-        "k_final": 0,
+        "k_prep": 0,                                       # lists and statistics: workspace traffic only
         "total": s * (5 * n + (nz + 7) * n_band),
     }
 
@@ -57,12 +60,13 @@ def pmc_traffic(kernel, nx, ny, nz):
     try:
         d = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, None
     c = d.get("config", {})
     if (c.get("nx"), c.get("ny"), c.get("nz")) != (nx, ny, nz):
-        return None
+        return None, None
     ks = d.get("kernels", {})
-    return (ks.get(kernel) or ks.get(kernel + "2") or {}).get("hbm_bytes")      # k_thc is k_thc2 on the default path
+    ent = ks.get(kernel) or ks.get(kernel + "3") or ks.get(kernel + "2") or {}
+    return ent.get("hbm_bytes"), d.get("source")
 
 
 def host_cores() -> int:
@@ -78,24 +82,48 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0, prec=8):
-    """Time the CPU oracle (our Fortran restatement of the reference, `kind: port`) on
-    this box's host cores: serial and all-core OpenMP, bounded by budget_s each."""
+def relerr(a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(np.abs(b.astype(np.float64)), REL_FLOOR)
+    d[np.isnan(a) & np.isnan(b)] = 0.0
+    return float(d.max()) if d.size else 0.0
+
+
+def cpu_baseline_and_parity(st, cdist, p, u, v, thetas, nz, gpu_states, timestep, budget_s=20.0, prec=8):
+    """The CPU oracle (our Fortran restatement of the reference, `kind: port`) on this box's host cores,
+    in two roles: (1) checker -- the step sequence tn = 1, 2, 15 (first step, ordinary step, a step whose
+    target_time branch fires) on the same inputs as the GPU ran it, compared field by field; (2) timed
+    baseline -- serial and all-core OpenMP, bounded by budget_s each."""
     from oracle.pyoracle import Oracle        # checker / baseline only
     ny, nx = st.ny, st.nx
-    out = {}
     ncores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
+    orc_omp = Oracle(prec, omp=True)
+    # ---- parity -----------------------------------------------------------------------------------
+    state = [np.zeros((ny, nx), p.dtype) for _ in range(4)]
+    names = ("windspeed", "winddir", "thc", "sb_con")
+    worst = {n: 0.0 for n in names}
+    pattern_equal = True
+    for (tn, inputs), gstate in zip(gpu_states["steps"], gpu_states["states"]):
+        pp, uu, vv, th = inputs
+        orc_omp.seabreeze_diag(timestep, tn, pp, uu, vv, th, cdist, st.z, st.sigma, *state, halo=0, bnd=1, omp=True)
+        for nme, a, b in zip(names, gstate, state):
+            worst[nme] = max(worst[nme], relerr(a, b))
+        pattern_equal = pattern_equal and bool(np.array_equal(gstate[3] != 0, state[3] != 0))
+    parity = {"max_rel_err": worst, "rel_floor": REL_FLOOR, "tolerance": 1e-6,
+              "steps": [tn for tn, _ in gpu_states["steps"]], "trigger_pattern_equal": pattern_equal,
+              "checker": "oracle/sb_oracle.f90 (OpenMP build), same inputs and step sequence",
+              "ok": bool(all(v < 1e-6 for v in worst.values()) and pattern_equal)}
+    # ---- timing -----------------------------------------------------------------------------------
+    out = {}
     for name, omp in (("serial", False), ("omp", True)):
-        if omp:
-            os.environ["OMP_NUM_THREADS"] = str(ncores)
-        orc = Oracle(prec, omp=omp)
+        orc = orc_omp if omp else Oracle(prec)
         state = [np.zeros((ny, nx), p.dtype) for _ in range(4)]
         times = []
         t_all = time.perf_counter()
         tn = 1
         while True:
             t0 = time.perf_counter()
-            orc.seabreeze_diag(1440.0, tn, p, u, v, theta, cdist, st.z, st.sigma, *state, halo=0, bnd=1, omp=omp)
+            orc.seabreeze_diag(timestep, tn, p, u, v, thetas[0], cdist, st.z, st.sigma, *state, halo=0, bnd=1, omp=omp)
             times.append(time.perf_counter() - t0)
             tn += 1
             if time.perf_counter() - t_all > budget_s or len(times) >= 12:
@@ -103,7 +131,43 @@ def cpu_baseline(st, cdist, p, u, v, theta, nz, budget_s=20.0, prec=8):
         # first call pays page faults; use the median of the rest when there is a rest
         med = float(np.median(times[1:])) if len(times) > 1 else times[0]
         out[name] = dict(s_per_call=med, calls=len(times))
-    return out, ncores
+    return out, ncores, parity
+
+
+def time_setup_kernels(ctx, torch, st, coast, dt, kwin, reps=5):
+    """get_edges / get_dist with device-resident arguments (SURVEY.md §8(d) secondary rows): HIP-event
+    median over `reps` launches each, algorithmic bytes 3*N*s each."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    lf, ic, co = up(st.landfrac), up(st.icefrac), up(coast)
+    out = torch.empty_like(lf)
+    stream = torch.cuda.current_stream().cuda_stream
+    ny, nx = st.ny, st.nx
+    esz = np.dtype(dt).itemsize
+    res = {}
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    ms = timed(lambda: ctx.get_edges_dev(dt, nx, ny, lf.data_ptr(), ic.data_ptr(), out.data_ptr(), stream=stream))
+    alg = 3 * nx * ny * esz
+    res["get_edges"] = {"ms": round(ms, 5), "algorithmic_bytes": alg, "achieved": alg / ms / 1e6,
+                        "frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+    ms = timed(lambda: ctx.get_dist_dev(dt, nx, ny, co.data_ptr(), lf.data_ptr(), st.lon, st.lat, out.data_ptr(),
+                                        kwin=kwin, stream=stream))
+    res["get_dist"] = {"ms": round(ms, 5), "algorithmic_bytes": alg, "achieved": alg / ms / 1e6,
+                       "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "window_half_width": kwin}
+    for k in res.values():
+        k["unit"] = "GB/s"
+    return res
 
 
 def main():
@@ -116,14 +180,16 @@ def main():
     ap.add_argument("--nz", type=int, default=56)
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="working precision (BASELINE configs[3], the N2560 grid, is quoted in fp32)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (baseline AND parity check)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline per variant")
     ap.add_argument("--comm", choices=("native", "torch", "gloo"), default="native",
                     help="N>1: ghost rows + moments over the library's own RCCL communicator (native; the "
                          "control plane is gloo), over torch.distributed's nccl backend (torch), or over gloo "
-                         "(rehearsal of the N>1 code path on a box with fewer GPUs than ranks)")
+                         "(rehearsal of the N>1 code path on a box with fewer GPUs than ranks).  A transport that "
+                         "cannot be initialised ends the run with a non-zero exit code: there is no silent fallback.")
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
+    ap.add_argument("--thc-threads", type=int, default=0, help="tuning: 512 or 1024 threads per k_thc3 workgroup")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +205,9 @@ def main():
     if args.comm == "gloo":
         local_rank %= max(1, torch.cuda.device_count())      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
+    # every launch of this run -- the library's kernels through the _dev entry points and the timing events --
+    # goes to one explicit stream (torch's default stream has handle 0, which the C ABI reads as "the context's own")
+    torch.cuda.set_stream(torch.cuda.Stream())
     comm = args.comm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -158,6 +227,8 @@ def main():
     t_gen = time.perf_counter()
     st = synth.static_fields(nx, ny, dt)
     ctx = hip.Context(local_rank)
+    if args.thc_threads:
+        ctx.set_thc_threads(args.thc_threads)
     if world > 1 and comm == "native":
         # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
         uid = [hip.comm_unique_id() if rank == 0 else None]
@@ -170,7 +241,13 @@ def main():
             ok[0] = 0
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok[0]) == 0:
-            comm = "torch"          # exchange through torch.distributed (gloo) instead: slow, still correct
+            # no silent change of transport: an N>1 number must be an RCCL number unless another was asked for
+            if rank == 0:
+                print("[bench] the library's RCCL communicator could not be initialised on every rank; "
+                      "rerun with --comm torch or --comm gloo to use another transport", file=sys.stderr, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     coast = ctx.get_edges(st.landfrac, st.icefrac)                    # HIP (product) setup chain
     cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     kwin = hip.dist_window(st.lon, st.lat)
@@ -192,11 +269,22 @@ def main():
     set_a = runner.upload_step_inputs(p_full, u_full, v_full, theta_a, local3d=True)
     set_b = runner.upload_step_inputs(p_full, v_full, u_full, theta_b, local3d=True)
     sets = (set_a, set_b)
+    host_sets = ((p_full, u_full, v_full, theta_a), (p_full, v_full, u_full, theta_b))
     timestep = 1440.0    # s; target_time branch fires every 15th step
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    # ---- parity sequence (single GPU): tn = 1, 2, 15 from a zero state, states kept for the checker ----
+    gpu_states = None
+    if world == 1 and not args.no_cpu_baseline:
+        gpu_states = {"steps": [], "states": []}
+        for tn in (1, 2, 15):
+            runner.step(timestep, tn, sets[tn % 2])
+            torch.cuda.synchronize()
+            gpu_states["steps"].append((tn, host_sets[tn % 2]))
+            gpu_states["states"].append([t.cpu().numpy().copy() for t in (runner.ws, runner.wd, runner.thc, runner.sb_con)])
 
     tn = 1
     for _ in range(W):
@@ -218,6 +306,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- per-step HIP-event times (median): a K-step pass of its own -----------------
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    evs[0].record()
+    for i in range(K):
+        runner.step(timestep, tn, sets[tn % 2]); tn += 1
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(K)])
+    median_ms = float(np.median(step_ms))
+
     # ---- per-kernel HIP-event timing (same stream, same inputs, live in this run) -------
     if not events_inside:
         ctx.profile_begin(K * args.profile_passes)
@@ -236,6 +334,7 @@ def main():
     dom = max(knames, key=lambda k: kern_ms[k])
     dom_gbs = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     call_gbs = ab["total"] / (elapsed / K) / 1e9
+    traffic, traffic_src = pmc_traffic(dom, nx, ny, nz) if world == 1 else (None, None)
 
     result = {
         "metric": "grid-points/sec for sea_breeze_diag on N2560x1920 global grid; achieved HBM GB/s",
@@ -245,6 +344,8 @@ def main():
         "steps": K,
         "warmup": W,
         "ms_per_step": ms_per_step,
+        "median_ms_per_step": median_ms,
+        "value_median": nx * ny / (median_ms * 1e-3),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -258,6 +359,7 @@ def main():
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
             "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
+            "multi_rank_rccl": "unmeasured on hardware so far (one GPU per box in the build pool)" if world == 1 else "this run",
             "input_gen_s": round(gen_s, 1),
         },
         "roofline": {
@@ -267,18 +369,24 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": dom_gbs / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(dom, nx, ny, nz) if world == 1 else None,
+            "traffic": traffic,
+            "traffic_source": ("committed rocprofv3 PMC passes of this command: " + ", ".join(traffic_src)) if traffic_src else None,
             "algorithmic_bytes_per_launch": ab[dom],
             "kernel_ms": {k: round(vv, 5) for k, vv in kern_ms.items()},
             "kernel_algorithmic_bytes": {k: ab[k] for k in knames},
+            "kernel_frac": {k: (ab[k] / (kern_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms[k] > 0 else None) for k in knames},
             "event_calls": ncalls,
             "whole_call": {"algorithmic_bytes": ab["total"], "achieved": call_gbs, "frac": call_gbs / HBM_PEAK_GBS},
             "rank0_counters": counters,
         },
     }
 
+    if rank == 0 and world == 1:
+        result["secondary"] = time_setup_kernels(ctx, torch, st, coast, dt, kwin)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ncores = cpu_baseline(st, cdist, p_full, u_full, v_full, theta_a, nz, args.cpu_budget, prec=esz)
+        cb, ncores, parity = cpu_baseline_and_parity(st, cdist, p_full, u_full, v_full, (theta_a, theta_b), nz,
+                                                     gpu_states, timestep, args.cpu_budget, prec=esz)
+        result["parity"] = parity
         result["cpu_baseline"] = {
             "value": nx * ny / cb["omp"]["s_per_call"],
             "unit": "grid-points/s",
@@ -295,6 +403,9 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and "parity" in result and not result["parity"]["ok"]:
+        print("[bench] PARITY FAILURE: the GPU outputs differ from the CPU oracle beyond 1e-6", file=sys.stderr)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -8,11 +8,21 @@
 ! linked against the drop-in modules of this directory, i.e. against libseabreeze_hip.so.
 ! BASELINE.json configs[0]: a 96x72 synthetic coastline.
 !
-! Usage:  dummy_model <input.bin> <output.bin> <nsteps>
+! Usage:  dummy_model <input.bin> <output.bin> <nsteps> [mode ...]
 !   input.bin : nx ny nz halo (4 x int32), then REAL arrays in Fortran order:
 !               lon(nx) lat(ny) land_frac(nx,ny) ice_frac(nx,ny) z(nx,ny) sigma(nx,ny)
 !               p(nx,ny,nz), then per step: theta(nx,ny) u(nx,ny,nz) v(nx,ny,nz)
 !   output.bin: cdist(nx,ny), then per step: sb_con windspeed winddir thc (nx,ny each)
+!   mode (optional):
+!     host                       the reference's call shape: host arrays in, host arrays out (default)
+!     dev                        the fields live on the device (sb_dev_alloc); per step only theta, u, v go up
+!                                and the four outputs come back; seabreeze_diag_dev
+!     band <rank> <nranks> <idfile>
+!                                one process per GPU, this one owns latitude band <rank> of <nranks>: the
+!                                RCCL id travels through <idfile> (a real host model would MPI_Bcast it),
+!                                static fields get their ghost rows once through swap_bounds, every step is one
+!                                band_seabreeze_diag; output.bin then holds this band's rows only
+!                                (cdist(nx,nyl), then per step the four (nx,nyl) fields)
 ! The tests write input.bin with numpy and compare output.bin with the CPU oracle.
 !
 ! Two deliberate differences from the outline, both documented in INTEGRATION.md:
@@ -35,20 +45,30 @@ module model_fields
 end module model_fields
 
 program dummy_model
+  use iso_c_binding
   use model_fields
   implicit none
-  character(len=512) :: fin, fout, arg
-  integer :: nsteps, step, uin, uout
+  character(len=512) :: fin, fout, arg, mode, idfile
+  integer :: nsteps, step, uin, uout, rank, nranks
   integer(4) :: hdr(4)
 
   if (command_argument_count() < 3) then
-    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps>'
+    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps> [host | dev | band <rank> <nranks> <idfile>]'
     error stop 2
   end if
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
   call get_command_argument(3, arg)
   read (arg, *) nsteps
+  mode = 'host'
+  if (command_argument_count() >= 4) call get_command_argument(4, mode)
+  rank = 0; nranks = 1
+  if (trim(mode) == 'band') then
+    if (command_argument_count() < 7) error stop 'band mode needs <rank> <nranks> <idfile>'
+    call get_command_argument(5, arg); read (arg, *) rank
+    call get_command_argument(6, arg); read (arg, *) nranks
+    call get_command_argument(7, idfile)
+  end if
 
   open (newunit=uin, file=trim(fin), access='stream', form='unformatted', status='old')
   read (uin) hdr
@@ -61,15 +81,24 @@ program dummy_model
   sb_con = 0.; windspeed = 0.; winddir = 0.; thc = 0.
 
   open (newunit=uout, file=trim(fout), access='stream', form='unformatted', status='replace')
-  do step = 1, nsteps
-    timestep_number = step
-    read (uin) theta, u, v
-    call atmos_step()
-    if (step == 1) write (uout) cdist
-    write (uout) sb_con, windspeed, winddir, thc
-  end do
+  select case (trim(mode))
+  case ('host')
+    do step = 1, nsteps
+      timestep_number = step
+      read (uin) theta, u, v
+      call atmos_step()
+      if (step == 1) write (uout) cdist
+      write (uout) sb_con, windspeed, winddir, thc
+    end do
+  case ('dev')
+    call run_device_resident()
+  case ('band')
+    call run_band()
+  case default
+    error stop 'unknown mode'
+  end select
   close (uin); close (uout)
-  print '(a,i0,a,i0,a,i0,a,es12.5)', 'dummy_model: ', nsteps, ' steps on ', nx, 'x', ny, &
+  print '(a,a,a,i0,a,i0,a,i0,a,es12.5)', 'dummy_model (', trim(mode), '): ', nsteps, ' steps on ', nx, 'x', ny, &
         ', sum(sb_con) = ', sum(sb_con)
 
 contains
@@ -90,5 +119,130 @@ contains
     integer, intent(in) :: timestep_number
     call seabreeze_diag(timestep, timestep_number, p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con)
   end subroutine physics
+
+  !---------------------------------------------------------------------------
+  ! fields resident on the device: static ones go up once, per step theta, u, v
+  !---------------------------------------------------------------------------
+  subroutine run_device_resident()
+    use sea_breeze_diag_mod, only : get_edges, get_dist, seabreeze_diag_dev
+    use sb_context_mod, only : sb_dev_alloc, sb_dev_free, sb_dev_upload, sb_dev_download
+    type(c_ptr) :: d_p, d_u, d_v, d_th, d_mask, d_z, d_sg, d_ws, d_wd, d_thc, d_sb
+    integer(c_size_t) :: b2, b3
+    real, target, allocatable :: buf2(:,:), buf3(:,:,:)
+    b2 = int(nx, c_size_t) * ny * (storage_size(theta) / 8)
+    b3 = b2 * nz
+    call get_edges(mask, ice_frac, land_frac, halo_size)
+    call get_dist(mask, land_frac, lon, lat, 180, cdist, halo_size)
+    write (uout) cdist
+    d_p = sb_dev_alloc(b3); d_u = sb_dev_alloc(b3); d_v = sb_dev_alloc(b3)
+    d_th = sb_dev_alloc(b2); d_mask = sb_dev_alloc(b2); d_z = sb_dev_alloc(b2); d_sg = sb_dev_alloc(b2)
+    d_ws = sb_dev_alloc(b2); d_wd = sb_dev_alloc(b2); d_thc = sb_dev_alloc(b2); d_sb = sb_dev_alloc(b2)
+    allocate(buf2(nx,ny), buf3(nx,ny,nz))
+    buf3 = p;      call sb_dev_upload(d_p, c_loc(buf3), b3)
+    buf2 = cdist;  call sb_dev_upload(d_mask, c_loc(buf2), b2)
+    buf2 = z;      call sb_dev_upload(d_z, c_loc(buf2), b2)
+    buf2 = sigma;  call sb_dev_upload(d_sg, c_loc(buf2), b2)
+    buf2 = 0.
+    call sb_dev_upload(d_ws, c_loc(buf2), b2); call sb_dev_upload(d_wd, c_loc(buf2), b2)
+    call sb_dev_upload(d_thc, c_loc(buf2), b2); call sb_dev_upload(d_sb, c_loc(buf2), b2)
+    do step = 1, nsteps
+      read (uin) theta, u, v
+      buf2 = theta; call sb_dev_upload(d_th, c_loc(buf2), b2)
+      buf3 = u;     call sb_dev_upload(d_u, c_loc(buf3), b3)
+      buf3 = v;     call sb_dev_upload(d_v, c_loc(buf3), b3)
+      call seabreeze_diag_dev(timestep, step, nx, ny, nz, 0, d_p, d_u, d_v, d_th, d_mask, d_z, d_sg, &
+                              d_ws, d_wd, d_thc, d_sb)
+      call sb_dev_download(c_loc(buf2), d_sb, b2);  sb_con = buf2
+      call sb_dev_download(c_loc(buf2), d_ws, b2);  windspeed = buf2
+      call sb_dev_download(c_loc(buf2), d_wd, b2);  winddir = buf2
+      call sb_dev_download(c_loc(buf2), d_thc, b2); thc = buf2
+      write (uout) sb_con, windspeed, winddir, thc
+    end do
+    call sb_dev_free(d_p); call sb_dev_free(d_u); call sb_dev_free(d_v); call sb_dev_free(d_th)
+    call sb_dev_free(d_mask); call sb_dev_free(d_z); call sb_dev_free(d_sg)
+    call sb_dev_free(d_ws); call sb_dev_free(d_wd); call sb_dev_free(d_thc); call sb_dev_free(d_sb)
+  end subroutine run_device_resident
+
+  !---------------------------------------------------------------------------
+  ! one latitude band of a multi-GPU run
+  !---------------------------------------------------------------------------
+  subroutine run_band()
+    use sea_breeze_diag_mod, only : get_edges, get_dist, band_seabreeze_diag
+    use halo_exchange_mod, only : swap_bounds
+    use sb_context_mod, only : sb_comm_get_unique_id, sb_comm_init, sb_comm_finalize
+    integer(c_signed_char) :: id(128)
+    integer :: r0, r1, nyl, h, base, rem, uid, ios, tries
+    real, allocatable :: th_b(:,:), mask_b(:,:), z_b(:,:), sg_b(:,:)
+    real, allocatable :: p_b(:,:,:), u_b(:,:,:), v_b(:,:,:)
+    real, allocatable :: ws_b(:,:), wd_b(:,:), thc_b(:,:), sb_b(:,:)
+    logical :: there
+
+    ! get_dist looks +-halo_size cells around every coast cell, so a band cell can be halo_size + 1 cells from
+    ! the nearest cell of the other class: that is the ghost width the contrast window needs
+    h = halo_size + 1
+    ! the setup chain works on the global static fields and runs before the communicator exists
+    ! (swap_bounds inside get_edges is then the single-domain fill)
+    call get_edges(mask, ice_frac, land_frac, halo_size)
+    call get_dist(mask, land_frac, lon, lat, 180, cdist, halo_size)
+    ! the RCCL id: rank 0 makes it, the others wait for the file
+    if (rank == 0) then
+      call sb_comm_get_unique_id(id)
+      open (newunit=uid, file=trim(idfile)//'.tmp', access='stream', form='unformatted', status='replace')
+      write (uid) id
+      close (uid)
+      call rename(trim(idfile)//'.tmp', trim(idfile))
+    else
+      do tries = 1, 6000
+        inquire (file=trim(idfile), exist=there)
+        if (there) exit
+        call sleep_ms(10)
+      end do
+      if (.not. there) error stop 'band mode: the id file never appeared'
+      open (newunit=uid, file=trim(idfile), access='stream', form='unformatted', status='old', iostat=ios)
+      read (uid) id
+      close (uid)
+    end if
+    call sb_comm_init(id, rank, nranks)
+    ! contiguous, near-equal bands
+    base = ny / nranks; rem = mod(ny, nranks)
+    r0 = rank * base + min(rank, rem) + 1
+    nyl = base + merge(1, 0, rank < rem)
+    r1 = r0 + nyl - 1
+    allocate(th_b(nx+2*h, nyl+2*h), mask_b(nx+2*h, nyl+2*h), z_b(nx+2*h, nyl+2*h), sg_b(nx+2*h, nyl+2*h))
+    allocate(p_b(nx,nyl,nz), u_b(nx,nyl,nz), v_b(nx,nyl,nz))
+    allocate(ws_b(nx,nyl), wd_b(nx,nyl), thc_b(nx,nyl), sb_b(nx,nyl))
+    ws_b = 0.; wd_b = 0.; thc_b = 0.; sb_b = 0.
+    mask_b = 0.; z_b = 0.; sg_b = 0.; th_b = 0.
+    mask_b(1+h:nx+h, 1+h:nyl+h) = cdist(:, r0:r1)
+    z_b(1+h:nx+h, 1+h:nyl+h) = z(:, r0:r1)
+    sg_b(1+h:nx+h, 1+h:nyl+h) = sigma(:, r0:r1)
+    ! static fields: ghost cells once (RCCL send/recv with the band neighbours, poles and E-W locally)
+    call swap_bounds(mask_b, h)
+    call swap_bounds(z_b, h)
+    call swap_bounds(sg_b, h)
+    p_b = p(:, r0:r1, :)
+    write (uout) cdist(:, r0:r1)
+    do step = 1, nsteps
+      read (uin) theta, u, v
+      th_b(1+h:nx+h, 1+h:nyl+h) = theta(:, r0:r1)
+      u_b = u(:, r0:r1, :)
+      v_b = v(:, r0:r1, :)
+      call band_seabreeze_diag(timestep, step, p_b, u_b, v_b, th_b, mask_b, z_b, sg_b, ws_b, wd_b, thc_b, sb_b)
+      write (uout) sb_b, ws_b, wd_b, thc_b
+    end do
+    sb_con = 0.
+    sb_con(:, r0:r1) = sb_b
+    call sb_comm_finalize()
+  end subroutine run_band
+
+  subroutine sleep_ms(ms)
+    integer, intent(in) :: ms
+    integer(8) :: c0, c1, rate
+    call system_clock(c0, rate)
+    do
+      call system_clock(c1)
+      if ((c1 - c0) * 1000 >= int(ms, 8) * rate) exit
+    end do
+  end subroutine sleep_ms
 
 end program dummy_model

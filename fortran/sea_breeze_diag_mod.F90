@@ -12,6 +12,14 @@
 !   amdflang ...                              -> REAL = 4 bytes -> sb_*_f32
 !   amdflang -fdefault-real-8 -DSB_REAL8 ...  -> REAL = 8 bytes -> sb_*_f64
 !
+! Beyond the reference's four routines (same names, same dummies) the module offers what a host
+! model needs to use more than one GPU or to keep its fields on the device:
+!   band_seabreeze_diag      one step of a latitude band (host arrays, ghost cells of width h): the
+!                            sigma statistics are reduced over all bands and theta's ghost rows are
+!                            exchanged over RCCL inside the call (sb_context_mod::sb_comm_init first)
+!   seabreeze_diag_dev,      the same two calls with every array a device pointer (type(c_ptr) from
+!   band_seabreeze_diag_dev  sb_context_mod::sb_dev_alloc): enqueue only, nothing crosses PCIe
+!
 ! Errors: the reference's generic routines have no error channel; a non-zero status from
 ! the library ends the run with `error stop` and the library's message.  The UM hook's
 ! `error` out-argument (ref: UM/vn10.7/sea_breeze_diag.F90:102) is available through
@@ -27,9 +35,11 @@
 !===============================================================================
 module sea_breeze_diag_mod
   use iso_c_binding
+  use sb_context_mod, only : ctx => sb_ctx, ensure_ctx => sb_ensure_ctx, fail => sb_fail, sb_release_ctx
   implicit none
   private
   public :: seabreeze_diag, seabreeze_diag_status, get_edges, get_dist, sigmoid, sb_shutdown
+  public :: band_seabreeze_diag, seabreeze_diag_dev, band_seabreeze_diag_dev
 
 #ifdef SB_REAL8
   integer, parameter :: rk = c_double
@@ -37,17 +47,21 @@ module sea_breeze_diag_mod
 #define SB_SIGMOID        "sb_sigmoid_f64"
 #define SB_GET_EDGES      "sb_get_edges_f64"
 #define SB_GET_DIST       "sb_get_dist_f64"
+#define SB_BAND_DIAG      "sb_band_seabreeze_diag_f64"
+#define SB_DIAG_DEV       "sb_seabreeze_diag_f64_dev"
+#define SB_BAND_DIAG_DEV  "sb_band_seabreeze_diag_f64_dev"
 #else
   integer, parameter :: rk = c_float
 #define SB_SEABREEZE_DIAG "sb_seabreeze_diag_f32"
 #define SB_SIGMOID        "sb_sigmoid_f32"
 #define SB_GET_EDGES      "sb_get_edges_f32"
 #define SB_GET_DIST       "sb_get_dist_f32"
+#define SB_BAND_DIAG      "sb_band_seabreeze_diag_f32"
+#define SB_DIAG_DEV       "sb_seabreeze_diag_f32_dev"
+#define SB_BAND_DIAG_DEV  "sb_band_seabreeze_diag_f32_dev"
 #endif
 
   integer(c_int), parameter :: SB_BND_GLOBAL = 1, SB_BND_HALO = 2
-
-  type(c_ptr), save :: ctx = c_null_ptr
 
   interface get_dist            ! the reference's caller passes the integer literal 180 for
     module procedure get_dist_r ! maxdist (ref: generic/dummy_model.f90:33); accept both
@@ -55,19 +69,6 @@ module sea_breeze_diag_mod
   end interface
 
   interface
-    integer(c_int) function sb_create(ctx, device) bind(C, name="sb_create")
-      import :: c_ptr, c_int
-      type(c_ptr), intent(out) :: ctx
-      integer(c_int), value :: device
-    end function
-    integer(c_int) function sb_destroy(ctx) bind(C, name="sb_destroy")
-      import :: c_ptr, c_int
-      type(c_ptr), value :: ctx
-    end function
-    type(c_ptr) function sb_last_error(ctx) bind(C, name="sb_last_error")
-      import :: c_ptr
-      type(c_ptr), value :: ctx
-    end function
     integer(c_int) function c_seabreeze_diag(ctx, timestep, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, &
         z, sigma, ws, wd, thc, sb_con, tun) bind(C, name=SB_SEABREEZE_DIAG)
       import :: c_ptr, c_int, rk
@@ -76,6 +77,29 @@ module sea_breeze_diag_mod
       integer(c_int), value :: tn, nx, ny, nz, halo, bnd
       real(rk), intent(in) :: p(*), u(*), v(*), theta(*), mask(*), z(*), sigma(*)
       real(rk), intent(inout) :: ws(*), wd(*), thc(*), sb_con(*)
+    end function
+    integer(c_int) function c_band_diag(ctx, timestep, tn, nx, ny, nz, halo, p, u, v, theta, mask, &
+        z, sigma, ws, wd, thc, sb_con, tun) bind(C, name=SB_BAND_DIAG)
+      import :: c_ptr, c_int, rk
+      type(c_ptr), value :: ctx, tun
+      real(rk), value :: timestep
+      integer(c_int), value :: tn, nx, ny, nz, halo
+      real(rk), intent(in) :: p(*), u(*), v(*), mask(*), z(*), sigma(*)
+      real(rk), intent(inout) :: theta(*), ws(*), wd(*), thc(*), sb_con(*)
+    end function
+    integer(c_int) function c_diag_dev(ctx, timestep, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, &
+        z, sigma, ws, wd, thc, sb_con, tun, stream) bind(C, name=SB_DIAG_DEV)
+      import :: c_ptr, c_int, rk
+      type(c_ptr), value :: ctx, tun, stream, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con
+      real(rk), value :: timestep
+      integer(c_int), value :: tn, nx, ny, nz, halo, bnd
+    end function
+    integer(c_int) function c_band_diag_dev(ctx, timestep, tn, nx, ny, nz, halo, p, u, v, theta, mask, &
+        z, sigma, ws, wd, thc, sb_con, tun, stream) bind(C, name=SB_BAND_DIAG_DEV)
+      import :: c_ptr, c_int, rk
+      type(c_ptr), value :: ctx, tun, stream, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con
+      real(rk), value :: timestep
+      integer(c_int), value :: tn, nx, ny, nz, halo
     end function
     integer(c_int) function c_sigmoid(ctx, nx, ny, ary, sm) bind(C, name=SB_SIGMOID)
       import :: c_ptr, c_int, rk
@@ -104,39 +128,9 @@ module sea_breeze_diag_mod
 
 contains
 
-  subroutine ensure_ctx()
-    integer(c_int) :: rc
-    if (.not. c_associated(ctx)) then
-      rc = sb_create(ctx, -1_c_int)
-      if (rc /= 0) call fail('sb_create', rc)
-    end if
-  end subroutine ensure_ctx
-
-  subroutine fail(what, rc)
-    character(len=*), intent(in) :: what
-    integer(c_int), intent(in) :: rc
-    character(kind=c_char), pointer :: msg(:)
-    character(len=512) :: text
-    type(c_ptr) :: cp
-    integer :: i
-    text = ''
-    cp = sb_last_error(ctx)
-    if (c_associated(cp)) then
-      call c_f_pointer(cp, msg, [512])
-      do i = 1, 512
-        if (msg(i) == c_null_char) exit
-        text(i:i) = msg(i)
-      end do
-    end if
-    write (*, '(a,a,a,i0,a,a)') 'sea_breeze_diag_mod: ', what, ' failed (', rc, '): ', trim(text)
-    error stop 1
-  end subroutine fail
-
   !> Release the device context (optional; a host model may call it at shutdown).
   subroutine sb_shutdown()
-    integer(c_int) :: rc
-    if (c_associated(ctx)) rc = sb_destroy(ctx)
-    ctx = c_null_ptr
+    call sb_release_ctx()
   end subroutine sb_shutdown
 
   !---------------------------------------------------------------------------
@@ -184,6 +178,72 @@ contains
     error = c_seabreeze_diag(ctx, real(timestep, rk), int(timestep_number, c_int), nx, ny, nz, h, bnd, &
                              p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con, c_null_ptr)
   end subroutine seabreeze_diag_status
+
+  !---------------------------------------------------------------------------
+  ! One step of a latitude band of a multi-GPU run (one process per GPU, sb_comm_init done).
+  ! Arguments as seabreeze_diag for this band's rows; theta, mask, z, sigma carry h ghost cells
+  ! all round ((nx+2h, ny+2h), h >= 1).  mask, z, sigma are static: fill their ghost cells once
+  ! with halo_exchange_mod::swap_bounds.  theta's ghost cells are filled inside the call (and
+  ! returned), overlapped with the kernels that do not need them; the sigma statistics are
+  ! reduced over all bands, so every band reproduces the rows of the single-domain result.
+  ! ref: generic/sea_breeze_diag.f90:55-271 + the exchange its UM twin makes,
+  !      UM/vn10.7/sea_breeze_diag.F90:408-410
+  !---------------------------------------------------------------------------
+  subroutine band_seabreeze_diag(timestep, timestep_number, &
+      p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con)
+    integer, intent(in) :: timestep_number
+    real, intent(in), contiguous :: p(:,:,:), u(:,:,:), v(:,:,:)
+    real, intent(in) :: timestep
+    real, intent(inout), contiguous :: theta(:,:)
+    real, intent(in), contiguous :: mask(:,:), z(:,:), sigma(:,:)
+    real, intent(inout), contiguous :: sb_con(:,:), windspeed(:,:), winddir(:,:), thc(:,:)
+    integer(c_int) :: nx, ny, nz, h, rc
+    nx = size(p, 1); ny = size(p, 2); nz = size(p, 3)
+    h = (size(theta, 1) - nx) / 2
+    if (h < 1 .or. size(theta, 1) /= nx + 2*h .or. size(theta, 2) /= ny + 2*h .or. &
+        any(shape(mask) /= shape(theta)) .or. any(shape(z) /= shape(theta)) .or. any(shape(sigma) /= shape(theta)) .or. &
+        any(shape(u) /= shape(p)) .or. any(shape(v) /= shape(p)) .or. &
+        any(shape(windspeed) /= [nx, ny]) .or. any(shape(winddir) /= [nx, ny]) .or. &
+        any(shape(thc) /= [nx, ny]) .or. any(shape(sb_con) /= [nx, ny])) &
+      call fail('band_seabreeze_diag: theta, mask, z, sigma must be (nx+2h, ny+2h) with h >= 1', 1_c_int)
+    call ensure_ctx()
+    rc = c_band_diag(ctx, real(timestep, rk), int(timestep_number, c_int), nx, ny, nz, h, &
+                     p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con, c_null_ptr)
+    if (rc /= 0) call fail('band_seabreeze_diag', rc)
+  end subroutine band_seabreeze_diag
+
+  !---------------------------------------------------------------------------
+  ! Device-resident forms: every array argument is a device pointer (sb_context_mod::sb_dev_alloc),
+  ! Fortran order as above; the call only enqueues on the context's stream
+  ! (sb_context_mod::sb_device_synchronize waits).  halo = 0: single global domain.
+  !---------------------------------------------------------------------------
+  subroutine seabreeze_diag_dev(timestep, timestep_number, nx, ny, nz, halo, &
+      p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con)
+    integer, intent(in) :: timestep_number, nx, ny, nz, halo
+    real, intent(in) :: timestep
+    type(c_ptr), intent(in) :: p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con
+    integer(c_int) :: rc, bnd
+    bnd = SB_BND_GLOBAL
+    if (halo > 0) bnd = SB_BND_HALO
+    call ensure_ctx()
+    rc = c_diag_dev(ctx, real(timestep, rk), int(timestep_number, c_int), int(nx, c_int), int(ny, c_int), &
+                    int(nz, c_int), int(halo, c_int), bnd, p, u, v, theta, mask, z, sigma, &
+                    windspeed, winddir, thc, sb_con, c_null_ptr, c_null_ptr)
+    if (rc /= 0) call fail('seabreeze_diag_dev', rc)
+  end subroutine seabreeze_diag_dev
+
+  subroutine band_seabreeze_diag_dev(timestep, timestep_number, nx, ny, nz, halo, &
+      p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con)
+    integer, intent(in) :: timestep_number, nx, ny, nz, halo
+    real, intent(in) :: timestep
+    type(c_ptr), intent(in) :: p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con
+    integer(c_int) :: rc
+    call ensure_ctx()
+    rc = c_band_diag_dev(ctx, real(timestep, rk), int(timestep_number, c_int), int(nx, c_int), int(ny, c_int), &
+                         int(nz, c_int), int(halo, c_int), p, u, v, theta, mask, z, sigma, &
+                         windspeed, winddir, thc, sb_con, c_null_ptr, c_null_ptr)
+    if (rc /= 0) call fail('band_seabreeze_diag_dev', rc)
+  end subroutine band_seabreeze_diag_dev
 
   !---------------------------------------------------------------------------
   ! ref: generic/sea_breeze_diag.f90:273-373.  landfrac/icefrac are (nx, ny); the coast

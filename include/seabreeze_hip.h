@@ -87,17 +87,20 @@ int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
    while the grid has too few tiles to give every compute unit one), 32, 48 or 64 = forced.  A tuning
    and test knob: results never depend on it.                                          */
 int  sb_set_tile_rows(sb_ctx *ctx, int rows);
+/* Threads of the contrast kernel's workgroups for halos up to 16: 512 (8 waves of up to 256 registers, the
+   default) or 1024 (16 waves of up to 128).  A tuning and test knob: results never depend on it.       */
+int  sb_set_thc_threads(sb_ctx *ctx, int threads);
 /* Counters of the last diag call: [0] band cells, [1] cells that left the LDS path,
    [2] cells whose search found only one class (result NaN; the reference loops
    forever there, ref: generic/sea_breeze_diag.f90:191-214), [3] max radius used.
    Synchronises the context's stream.                                                */
 int  sb_last_counters(sb_ctx *ctx, long long counters[4]);
 int  sb_synchronize(sb_ctx *ctx);
-/* Per-kernel timing with HIP events on the stream(s) the kernels run on.  Between
-   sb_profile_begin and sb_profile_end the first `max_calls` diag calls record events around
-   their launches; sb_profile_end synchronises and returns the average duration in ms of
-   [0] k_scan (+ k_moments_final where it is still a launch) [1] k_wind [2] k_t0 (f2py flavour; empty for
-   the host-model flavour) [3] k_thc2 [4] unused.                                                        */
+/* Per-kernel timing with HIP events on the stream the kernels run on.  Between sb_profile_begin and
+   sb_profile_end the first `max_calls` diag calls record a pair of events around each of their
+   launches; sb_profile_end synchronises and returns the average duration in ms of
+   [0] k_scan [1] k_wind [2] k_t0 (f2py flavour only; 0 where a call does not launch it) [3] k_thc3
+   [4] k_prep.  An event interval also holds the gap to the previous launch (about 5 us).          */
 int  sb_profile_begin(sb_ctx *ctx, int max_calls);
 int  sb_profile_end(sb_ctx *ctx, double avg_ms[5], int *ncalls);
 
@@ -281,6 +284,35 @@ int sb_band_seabreeze_diag_f32_dev(sb_ctx *ctx, float timestep_s, int timestep_n
                                    const float *mask, const float *z, const float *sigma, float *windspeed,
                                    float *winddir, float *thc, float *sb_con, const sb_tunables *tun,
                                    void *stream);
+
+/* Host-pointer forms of the two for host models whose fields live in host memory (what the Fortran
+   modules fortran/halo_exchange_mod.f90 and fortran/sea_breeze_diag_mod.F90 bind): the arrays are staged
+   through device buffers of the context, the exchange runs over RCCL between the devices, the results come
+   back.  sb_swap_bounds_* replaces swap_bounds(field, halo_size), ref: generic/halo_exchange_mod.f90:12-17
+   and its call sites generic/sea_breeze_diag.f90:342,371; theta's ghost cells are filled on return from
+   sb_band_seabreeze_diag_*.                                                                          */
+int sb_swap_bounds_f64(sb_ctx *ctx, double *field, int nx, int ny, int halo);
+int sb_swap_bounds_f32(sb_ctx *ctx, float *field, int nx, int ny, int halo);
+int sb_band_seabreeze_diag_f64(sb_ctx *ctx, double timestep_s, int timestep_number, int nx, int ny, int nz,
+                               int halo, const double *p, const double *u, const double *v, double *theta,
+                               const double *mask, const double *z, const double *sigma, double *windspeed,
+                               double *winddir, double *thc, double *sb_con, const sb_tunables *tun);
+int sb_band_seabreeze_diag_f32(sb_ctx *ctx, float timestep_s, int timestep_number, int nx, int ny, int nz,
+                               int halo, const float *p, const float *u, const float *v, float *theta,
+                               const float *mask, const float *z, const float *sigma, float *windspeed,
+                               float *winddir, float *thc, float *sb_con, const sb_tunables *tun);
+/* rank of this context's band and the number of bands; nranks = 0 without a communicator */
+int sb_comm_rank(sb_ctx *ctx, int *rank, int *nranks);
+
+/* -------------------------------------------------------------------------------- */
+/* device memory for host models that keep their fields resident between calls      */
+/* (Fortran: type(c_ptr) handles passed to the _dev entry points); upload and         */
+/* download synchronise.                                                              */
+/* -------------------------------------------------------------------------------- */
+int sb_device_malloc(sb_ctx *ctx, size_t nbytes, void **dptr);
+int sb_device_free(sb_ctx *ctx, void *dptr);
+int sb_device_upload(sb_ctx *ctx, void *dst_dev, const void *src_host, size_t nbytes);
+int sb_device_download(sb_ctx *ctx, void *dst_host, const void *src_dev, size_t nbytes);
 
 /* -------------------------------------------------------------------------------- */
 /* get_threads  ref: sobel.f90:195-206 (OpenMP thread count there; here the number   */

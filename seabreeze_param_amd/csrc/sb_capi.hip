@@ -34,14 +34,16 @@ struct sb_ctx {
     int radius_hint = 16;
     int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc2 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
+    int thc_nt = 512;           // threads of a k_thc3 workgroup (sb_set_tuning)
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs, stamps, nws, nwd, coastbits;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps;
     int tiles_n = 0, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
     unsigned int *ticket = nullptr;
     void *stats = nullptr;      // 4 x double
     int *counters = nullptr;    // 2 ints
+    int *seg_count = nullptr;   // SB_SEG_PARTS ints: entries in each sub-list of segments (k_prep -> k_wind)
     // staging buffers for the host-pointer entry points
     std::vector<DevBuf> stage;
     // geometry of the last diag call (for sb_last_counters)
@@ -54,6 +56,7 @@ struct sb_ctx {
     hipEvent_t band_moments_event = nullptr;
     int ngathered = 0;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<unsigned> prof_mask;    // per profiled call: which kernels were launched
     int prof_calls = 0, prof_max = 0;
     // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
     hipStream_t aux_stream = nullptr;   // communication of a band step runs here
@@ -110,7 +113,7 @@ int pick_halo(const sb_ctx *c) {
     return SB_MAX_LDS_HALO;
 }
 
-// Prepare workspace + job; enqueue the four kernels of one diag call.
+// Prepare workspace + job; enqueue the kernels of one diag call.
 template <typename T>
 int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const Geo &g = job.g;
@@ -125,7 +128,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if (H > 8 && H <= 16 && c->tile_rows) tyrows = c->tile_rows;
     const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
-    // raises flags in this call's buffer, k_final clears the other one for the next call, so no
+    // raises flags in this call's buffer, k_wind clears the other one for the next call, so no
     // memset sits on the critical path and the last call's values stay readable.
     const int nflag = tx * ty + 2;
     if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag) {
@@ -144,11 +147,19 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.stats = (const T *)c->stats;
     job.tile_nnmax = flags_now;
     job.counters = flags_now + (size_t)tx * ty;
-    { static const bool stat = getenv("SB_THC_STATIC") != nullptr;    // diagnostic: static split of the tile list
-      job.ticket = stat ? nullptr : (int *)c->ticket; }
+    job.ticket = (int *)c->ticket;
     job.next_flags = flags_next;
     job.next_flags_n = nflag;
-    // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc2)
+    // the lists k_prep compacts: active tiles (k_thc3) and segments that hold band cells (k_wind)
+    if ((rc = ensure(c, c->tile_list, ((size_t)tx * ty + 1) * sizeof(int)))) return rc;
+    const size_t nseg = (size_t)g.nyh * g.nw;
+    const size_t seg_cap = (nseg + SB_SEG_PARTS - 1) / SB_SEG_PARTS;
+    if ((rc = ensure(c, c->seg_list, seg_cap * SB_SEG_PARTS * sizeof(SbSegEntry)))) return rc;
+    job.tile_list = (int *)c->tile_list.p;
+    job.seg_list = (SbSegEntry *)c->seg_list.p;
+    job.seg_count = c->seg_count;
+    job.seg_cap = (int)seg_cap;
+    // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc3)
     job.nws = job.nwd = nullptr;
     if (!(phases == 3 && !c->gathered)) {
         if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
@@ -156,11 +167,11 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
         job.nws = (T *)c->nws.p;
         job.nwd = (T *)c->nwd.p;
     }
-    // the host-model flavour derives t0 inside k_thc2; the f2py flavour returns the t0 plane
+    // the host-model flavour derives t0 inside k_thc3; the f2py flavour returns the t0 plane
     job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
-    // whole single-domain calls on the k_thc2 path: contrast first, k_wind applies the update
+    // whole single-domain calls: contrast first, k_wind applies the update
     job.wind_final = (phases == 3 && !c->gathered) ? 1 : 0;
-    // the t0 plane with its ghost cells: f2py flavour only (k_t0 -> k_thc2)
+    // the t0 plane with its ghost cells: f2py flavour only (k_t0 -> k_thc3)
     job.t0 = nullptr;
     if (!job.t0_fly) {
         if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
@@ -168,16 +179,19 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     job.stamps = nullptr;
 #ifdef SB_STAMPS
-    if ((rc = ensure(c, c->stamps, (size_t)tx * ty * SB_NSTAMP * sizeof(long long)))) return rc;
+    if ((rc = ensure(c, c->stamps, (size_t)4096 * SB_NSTAMP * sizeof(long long)))) return rc;
     job.stamps = (long long *)c->stamps.p;
-    HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, (size_t)tx * ty * SB_NSTAMP * sizeof(long long), st));
 #endif
     SbLaunchCtx lc;
     lc.stream = st;
     lc.prof = nullptr;
-    if (phases == 3 && c->prof_calls < c->prof_max) lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
+    lc.prof_mask = nullptr;
+    if (phases == 3 && c->prof_calls < c->prof_max) {
+        lc.prof_mask = &c->prof_mask[(size_t)c->prof_calls];
+        lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
+    }
     lc.partials = c->partials; lc.stats = c->stats;
-    lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
+    lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu; lc.thc_nt = c->thc_nt;
     lc.moments_out = (phases & 1) ? c->band_moments_out : nullptr;
     lc.moments_event = (phases & 1) ? c->band_moments_event : nullptr;
     lc.phases = phases;
@@ -608,6 +622,8 @@ int sb_create(sb_ctx **out, int device) {
               hipMalloc((void **)&c->ticket, sizeof(unsigned int)) == hipSuccess &&
               hipMalloc(&c->stats, 4 * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&c->counters, 2 * sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&c->seg_count, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
+              hipMemset(c->seg_count, 0, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
               hipMemset(c->ticket, 0, sizeof(unsigned int)) == hipSuccess &&
               hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess;
     if (!ok) {
@@ -629,7 +645,8 @@ int sb_destroy(sb_ctx *c) {
     if (c->band_mom.p) (void)hipFree(c->band_mom.p);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->stamps, &c->nws, &c->nwd, &c->coastbits})
+    for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->nws, &c->nwd, &c->coastbits, &c->tile_list,
+                      &c->seg_list, &c->stamps})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);
@@ -637,6 +654,7 @@ int sb_destroy(sb_ctx *c) {
     if (c->ticket) (void)hipFree(c->ticket);
     if (c->stats) (void)hipFree(c->stats);
     if (c->counters) (void)hipFree(c->counters);
+    if (c->seg_count) (void)hipFree(c->seg_count);
     delete c;
     return SB_OK;
 }
@@ -647,17 +665,6 @@ int sb_synchronize(sb_ctx *c) {
     return SB_OK;
 }
 
-#ifdef SB_STAMPS
-// diagnostic build only: copy the per-tile clock stamps of the last diag call to the host
-int sb_debug_stamps(sb_ctx *c, long long *host, int ntiles_max, int *ntiles) {
-    if (!c || !host || !ntiles || !c->have_last) return SB_ERR_ARG;
-    HIPCHK(c, hipDeviceSynchronize());
-    const int n = c->last_tiles < ntiles_max ? c->last_tiles : ntiles_max;
-    HIPCHK(c, hipMemcpy(host, c->stamps.p, (size_t)n * SB_NSTAMP * sizeof(long long), hipMemcpyDeviceToHost));
-    *ntiles = n;
-    return SB_OK;
-}
-#endif
 
 int sb_sigma_moments_f64_dev(sb_ctx *c, int nx, int ny, int halo, const double *sigma, double *m5, void *stream) {
     return sigma_moments_dev<double>(c, nx, ny, halo, sigma, m5, stream);
@@ -680,6 +687,7 @@ int sb_profile_begin(sb_ctx *c, int max_calls) {
     if (max_calls < 1 || max_calls > 100000) return fail(c, SB_ERR_ARG, "max_calls out of range");
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.assign((size_t)SB_PROF_EVENTS * max_calls, nullptr);
+    c->prof_mask.assign((size_t)max_calls, 0u);
     for (hipEvent_t &e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
     c->prof_calls = 0;
     c->prof_max = max_calls;
@@ -690,20 +698,23 @@ int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (!avg_ms || !ncalls) return fail(c, SB_ERR_ARG, "null pointer");
     HIPCHK(c, hipDeviceSynchronize());
-    // event pairs bracket k_scan (+ moments merge when it is a launch), k_wind, k_t0, k_thc2, (unused)
-    static const int first[SB_PROF_KERNELS] = {0, 2, 4, 5, 6}, last[SB_PROF_KERNELS] = {1, 3, 5, 6, 7};
+    // event pair k brackets kernel k (SB_PROF_*); a kernel a call did not launch has no interval
     double sum[SB_PROF_KERNELS] = {0, 0, 0, 0, 0};
+    int cnt[SB_PROF_KERNELS] = {0, 0, 0, 0, 0};
     for (int i = 0; i < c->prof_calls; ++i)
         for (int k = 0; k < SB_PROF_KERNELS; ++k) {
+            if (!((c->prof_mask[(size_t)i] >> k) & 1u)) continue;
             float ms = 0.f;
             const hipEvent_t *e = &c->prof_ev[(size_t)SB_PROF_EVENTS * i];
-            HIPCHK(c, hipEventElapsedTime(&ms, e[first[k]], e[last[k]]));
+            HIPCHK(c, hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1]));
             sum[k] += ms;
+            ++cnt[k];
         }
     *ncalls = c->prof_calls;
-    for (int k = 0; k < SB_PROF_KERNELS; ++k) avg_ms[k] = c->prof_calls ? sum[k] / c->prof_calls : 0.0;
+    for (int k = 0; k < SB_PROF_KERNELS; ++k) avg_ms[k] = cnt[k] ? sum[k] / cnt[k] : 0.0;
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
+    c->prof_mask.clear();
     c->prof_calls = c->prof_max = 0;
     return SB_OK;
 }
@@ -719,6 +730,23 @@ int sb_set_tile_rows(sb_ctx *c, int rows) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (rows != 0 && rows != 32 && rows != 48 && rows != 64) return fail(c, SB_ERR_ARG, "tile rows must be 0, 32, 48 or 64");
     c->tile_rows = rows;
+    return SB_OK;
+}
+
+#ifdef SB_STAMPS
+// diagnostic build only: the per-workgroup clock sums of the last k_thc3 launch
+int sb_debug_stamps(sb_ctx *c, long long *host, int nwg) {
+    if (!c || !host || !c->stamps.p) return SB_ERR_ARG;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(host, c->stamps.p, (size_t)nwg * SB_NSTAMP * sizeof(long long), hipMemcpyDeviceToHost));
+    return SB_OK;
+}
+#endif
+
+int sb_set_thc_threads(sb_ctx *c, int threads) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (threads != 512 && threads != 1024) return fail(c, SB_ERR_ARG, "contrast-kernel workgroups have 512 or 1024 threads");
+    c->thc_nt = threads;
     return SB_OK;
 }
 
@@ -938,6 +966,103 @@ int sb_swap_bounds_f64_dev(sb_ctx *c, double *field, int nx, int ny, int halo, v
 }
 int sb_swap_bounds_f32_dev(sb_ctx *c, float *field, int nx, int ny, int halo, void *stream) {
     return swap_bounds_dev<float>(c, field, nx, ny, halo, stream);
+}
+
+}  // extern "C"
+
+// ---- host-pointer forms for host models that keep their fields in host memory (the Fortran modules) ----
+namespace {
+template <typename T>
+int swap_bounds_host(sb_ctx *c, T *field, int nx, int ny, int halo) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!field || nx < 1 || ny < 1 || halo < 0) return fail(c, SB_ERR_ARG, "bad swap_bounds arguments");
+    if (halo == 0) return SB_OK;
+    const size_t n = (size_t)(nx + 2 * halo) * (ny + 2 * halo);
+    Stager s(c);
+    T *d = s.in(field, n);
+    if (s.rc) return s.rc;
+    int rc = swap_bounds_dev<T>(c, d, nx, ny, halo, nullptr);
+    if (rc) return rc;
+    s.back(field, d, n);
+    return s.finish();
+}
+
+template <typename T>
+int band_diag_host(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, const T *p, const T *u, const T *v,
+                   T *theta, const T *mask, const T *z, const T *sigma, T *ws, T *wd, T *thc, T *sb_con,
+                   const sb_tunables *tun) {
+    int rc = check_dims<T>(c, nx, ny, nz, halo, SB_BND_HALO);
+    if (rc) return rc;
+    if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, n2h = (size_t)(nx + 2 * halo) * (ny + 2 * halo);
+    Stager s(c);
+    T *dp = s.in(p, n3), *du = s.in(u, n3), *dv = s.in(v, n3);
+    T *dth = s.in(theta, n2h), *dm = s.in(mask, n2h), *dz = s.in(z, n2h), *dsg = s.in(sigma, n2h);
+    T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2), *dsb = s.in(sb_con, n2);
+    if (s.rc) return s.rc;
+    rc = band_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, dp, du, dv, dth, dm, dz, dsg, dws, dwd, dthc, dsb, tun, nullptr);
+    if (rc) return rc;
+    s.back(theta, dth, n2h);                      // its ghost cells were filled by the exchange
+    s.back(ws, dws, n2); s.back(wd, dwd, n2); s.back(thc, dthc, n2); s.back(sb_con, dsb, n2);
+    return s.finish();
+}
+}  // namespace
+
+extern "C" {
+
+int sb_swap_bounds_f64(sb_ctx *c, double *field, int nx, int ny, int halo) { return swap_bounds_host<double>(c, field, nx, ny, halo); }
+int sb_swap_bounds_f32(sb_ctx *c, float *field, int nx, int ny, int halo) { return swap_bounds_host<float>(c, field, nx, ny, halo); }
+
+int sb_band_seabreeze_diag_f64(sb_ctx *c, double dt, int tn, int nx, int ny, int nz, int halo, const double *p,
+                               const double *u, const double *v, double *theta, const double *mask, const double *z,
+                               const double *sigma, double *ws, double *wd, double *thc, double *sb_con,
+                               const sb_tunables *tun) {
+    return band_diag_host<double>(c, dt, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con, tun);
+}
+int sb_band_seabreeze_diag_f32(sb_ctx *c, float dt, int tn, int nx, int ny, int nz, int halo, const float *p,
+                               const float *u, const float *v, float *theta, const float *mask, const float *z,
+                               const float *sigma, float *ws, float *wd, float *thc, float *sb_con,
+                               const sb_tunables *tun) {
+    return band_diag_host<float>(c, dt, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con, tun);
+}
+
+int sb_comm_rank(sb_ctx *c, int *rank, int *nranks) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!rank || !nranks) return fail(c, SB_ERR_ARG, "null pointer");
+    *rank = c->rank;
+    *nranks = c->comm ? c->nranks : 0;            // 0: no communicator
+    return SB_OK;
+}
+
+// device memory for host models that keep fields resident between calls (Fortran: type(c_ptr))
+int sb_device_malloc(sb_ctx *c, size_t nbytes, void **dptr) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!dptr) return fail(c, SB_ERR_ARG, "null pointer");
+    *dptr = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, nbytes ? nbytes : 8);
+    if (e != hipSuccess) return fail(c, SB_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SB_OK;
+}
+int sb_device_free(sb_ctx *c, void *dptr) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (dptr) HIPCHK(c, hipFree(dptr));
+    return SB_OK;
+}
+int sb_device_upload(sb_ctx *c, void *dst_dev, const void *src_host, size_t nbytes) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!dst_dev || !src_host) return fail(c, SB_ERR_ARG, "null pointer");
+    HIPCHK(c, hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SB_OK;
+}
+int sb_device_download(sb_ctx *c, void *dst_host, const void *src_dev, size_t nbytes) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!dst_host || !src_dev) return fail(c, SB_ERR_ARG, "null pointer");
+    HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SB_OK;
 }
 
 int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, void *stream) {

@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define SB_WAVE 64
-#define SB_NSTAMP 32                 // diagnostic build: clock stamps per thc tile
+#define SB_NSTAMP 16                 // diagnostic build: clock sums per k_thc3 workgroup
 
 enum { SB_FLAVOUR_GENERIC = 0, SB_FLAVOUR_WRAPPER = 1 };
 enum { BND_WRAPPER = 0, BND_GLOBAL = 1, BND_HALO = 2 };
@@ -52,6 +52,30 @@ __device__ __forceinline__ int sb_wave_scan_add(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// The same scan for doubles: the two 32-bit halves travel by DPP moves, the add is a plain v_add_f64 (DPP does
+// not apply to 64-bit VALU operations).  Lanes without a source receive +0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sb_dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sb_wave_scan_add_f64(double v) {
+    v += sb_dpp_f64<0x111, 0xf>(v);      // row_shr:1
+    v += sb_dpp_f64<0x112, 0xf>(v);      // row_shr:2
+    v += sb_dpp_f64<0x114, 0xf>(v);      // row_shr:4
+    v += sb_dpp_f64<0x118, 0xf>(v);      // row_shr:8
+    v += sb_dpp_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += sb_dpp_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// value of lane `l` (compile-time or wave-uniform) of a double, in every lane
+__device__ __forceinline__ double sb_readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 #define SB_STATS_NT 1024             // threads of every workgroup that merges moments
@@ -132,6 +156,14 @@ __device__ __forceinline__ bool sb_map_cell(const Geo &g, int xs, int ys, int &X
     return true;
 }
 
+// One 64-cell longitude segment that holds band cells, as k_prep lists it for k_wind: the index of the
+// segment in the bit planes (row * nw + word) and its band word.
+struct SbSegEntry {
+    uint64_t word;
+    uint32_t seg, pad;
+};
+#define SB_SEG_PARTS 16              // k_prep workgroups that compact the segment list, one sub-list each
+
 template <typename T>
 struct DiagJob {
     Geo g;
@@ -142,27 +174,36 @@ struct DiagJob {
     T target_plev, thr_wind, thr_dir, thr_ch, thr_thc, maxdist, fill;
     // inputs
     const T *p, *u, *v;             // generic: (nx,ny,nz); wrapper: p(nps), u/v (nx,ny,nps)
-    const T *theta, *mask, *z, *sigma;   // (nxh, nyh)
+    const T *theta, *mask, *z, *sigma;   // (nxh, nyh); mask may sit in a wider frame (UM layout): row pitch mask_ld,
+    int mask_ld;                    //   first cell of the (nxh, nyh) frame at mask[mask_off]
+    unsigned mask_off;
+    int level_rule;                 // 0: first minimum of |p - target| over all levels (generic :223);
+                                    // 1: the UM copy's upward walk that stops at the first increase (UM :265-274)
     // state / outputs, (nx, ny)
     T *ws, *wd, *thc, *sb_con;
     T *out;                         // wrapper: (nx,ny,4) packed output, else nullptr
     // workspace
-    T *nws, *nwd;                   // (nx, ny): this call's wind speed / direction at band cells (k_wind -> k_final)
-    int *next_flags;                // the other tile-flag buffer: k_final clears it for the next call
+    T *nws, *nwd;                   // (nx, ny): this call's wind speed / direction at band cells (k_wind -> k_thc3, band steps only)
+    int *next_flags;                // the other tile-flag buffer: k_wind clears it for the next call
     int next_flags_n;
-    int wind_final;                 // 1: k_wind applies thresholds + state update itself (k_thc2 ran before it and
+    int wind_final;                 // 1: k_wind applies thresholds + state update itself (k_thc3 ran before it and
                                     //    left thc); 0: k_wind leaves nws/nwd and the contrast kernel applies them
-    int t0_fly;                     // 1: k_thc derives t0 from theta,z,sigma while staging; 0: reads the t0 workspace
+    int t0_fly;                     // 1: k_thc3 derives t0 from theta,z,sigma while staging; 0: reads the t0 workspace
     T *t0;                          // (nxh, nyh)
     uint64_t *bandbits;             // nyh * nw words: interior cells with |mask| <= maxdist
     uint64_t *clsbits;              // nyh * nw words: mask >= 0 ("land side")
     const T *stats;                 // [0]=std  [1]=r  (sigmoid scalars)
     int thc_ty, thc_ntx, thc_nty;   // contrast-kernel tile rows and tile-grid shape
-    int thc_txs;                    // log2 of the tile width (6: 64 longitudes, k_thc; 5: 32, k_thc2)
-    int *tile_nnmax;                // per thc tile: 0 = no band cell; k_prep raises 1, k_thc leaves the largest radius
-    int *ticket;                    // k_thc2 draws list positions from it; k_scan zeroes it (nullptr: static split)
+    int thc_txs;                    // log2 of the tile width (5: 32 longitudes)
+    int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius
+    int *ticket;                    // spare device word (zeroed by k_scan)
+    // lists k_prep compacts between k_scan and the kernels that consume them
+    int *tile_list;                 // [0] = number of active tiles, [1..] their indices in row-major order
+    SbSegEntry *seg_list;           // SB_SEG_PARTS sub-lists of seg_cap entries: the segments that hold band cells
+    int *seg_count;                 // entries in each sub-list
+    int seg_cap;
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
-    long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock stamps per thc tile
+    long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock sums per k_thc3 workgroup
 };
 
 __device__ __forceinline__ int sb_bit(const uint64_t *bits, int nw, int X, int Y) {
@@ -184,13 +225,48 @@ __host__ __device__ inline T sb_modulo(T a, T p) {
     return r;
 }
 
+// 1/(1+exp(y)) in the working precision.  For doubles: exp by argument reduction to |r| <= ln2/2 (two-part ln2,
+// fused), a degree-13 Taylor polynomial (truncation 4e-18) and v_ldexp_f64; the reciprocal by v_rcp_f64 and two
+// Newton steps.  About 30 instructions against about 90 for libm's exp plus an IEEE division, and within 2 ulp
+// of them -- a sixth of the fp64 work of staging a coastal tile was this expression.
+template <typename T>
+__device__ __forceinline__ T sb_logistic_of_neg(T y) {        // returns 1 / (1 + exp(y))
+    return T(1) / (T(1) + exp(y));
+}
+template <>
+__device__ __forceinline__ double sb_logistic_of_neg<double>(double y) {
+    y = fmin(fmax(y, -708.0), 700.0);                         // beyond: 1 or 0 to the last bit
+    const double n = __builtin_rint(y * 1.4426950408889634);
+    double r = __builtin_fma(-n, 0.6931471805599453, y);
+    r = __builtin_fma(-n, 2.3190468138462996e-17, r);
+    double p = 1.6059043836821613e-10;                        // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);            // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);           // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);           // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);          // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);            // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);           // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);           // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);           // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);          // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);          // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double x = 1.0 + ldexp(p, (int)n);
+    double q = __builtin_amdgcn_rcp(x);
+    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
+    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
+    return q;
+}
+
 // t0 = theta - (gmma*z)*sigmoid(sigma)   ref: generic/sea_breeze_diag.f90:166-167,478-480
 // At sea level (z == 0) the product is a signed zero whatever the sigmoid, so theta comes
 // back bit for bit and the exp is skipped -- most cells of a coastal tile are ocean.
 template <typename T>
 __device__ __forceinline__ T sb_t0(T theta, T z, T sigma, T sd, T r) {
     if (z == T(0)) return theta;
-    return theta - ((T(-0.0060956) * z) * (T(1) / (T(1) + exp(-sd * (sigma - r)))));
+    return theta - ((T(-0.0060956) * z) * sb_logistic_of_neg<T>(-sd * (sigma - r)));
 }
 
 // Thresholds, scaling and state update of one band cell at linear index o, given this
@@ -209,7 +285,7 @@ __device__ __forceinline__ SbCellState<T> sb_trigger_load(const DiagJob<T> &job,
     return s;
 }
 
-template <typename T>
+template <typename T, bool STORE_THC = true>      // STORE_THC = false: thc already holds n_thc (k_thc3 wrote it)
 __device__ __forceinline__ void sb_trigger_update(const DiagJob<T> &job, size_t o, T n_thc,
                                                   const SbCellState<T> &st) {
     const T n_ws = st.n_ws, n_wd = st.n_wd;
@@ -225,7 +301,7 @@ __device__ __forceinline__ void sb_trigger_update(const DiagJob<T> &job, size_t 
         const T scale_thc = (thc_abs - job.thr_thc) / n_thc;
         sb = scale_thc * scale_wind;
     }
-    job.thc[o] = n_thc;                                          // ref :262
+    if constexpr (STORE_THC) job.thc[o] = n_thc;                 // ref :262
     if (job.flavour == SB_FLAVOUR_GENERIC) {
         job.sb_con[o] = sb;
         job.ws[o] = n_ws;                                        // ref :261 (every call)

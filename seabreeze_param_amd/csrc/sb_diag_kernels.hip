@@ -6,18 +6,21 @@
 //
 //   k_scan   one pass over sigma and mask: per-workgroup moments of sigma, the band and
 //            land-side bit planes, tile flags, and the fill value for every cell outside
-//            the coastal band; k_moments_final merges the moments -> std, r   [HBM stream]
-//   k_wind   per band cell (dense lanes): level nearest target_plev in the p column, wind
-//            speed / direction                                               [HBM gather]
+//            the coastal band                                                  [HBM stream]
+//   k_prep   18 workgroups: the moments merged into the sigmoid scalars, the tile flags
+//            compacted into the list of active tiles (for k_thc3), the band plane into the
+//            list of 64-cell segments that hold band cells (for k_wind)        [tiny]
 //   k_t0     f2py flavour only: the t0 plane is an output there               [HBM stream]
-//   k_thc    (sb_thc_kernel.hip) per active 64 x TY tile: t0 and its summed-area tables in
-//            LDS, bisection for the window radius -> thc, then thresholds, scaling and
-//            state update -> sb_con                                           [LDS]
+//   k_thc3   (sb_thc_kernel.hip) per active 32 x TY tile: t0 and its summed-area tables in
+//            LDS, two-round search for the window radius -> thc               [VALU + LDS]
+//   k_wind   per listed segment: level nearest target_plev in the p column of every band
+//            cell, wind speed / direction, thresholds, scaling, state update   [HBM gather]
 //
+// A band step of a multi-GPU run launches k_wind before its ghost rows arrive (it then leaves
+// this call's wind for k_thc3, which applies thresholds and update itself).
 // Memory-bound integer/fp64 work: no MFMA anywhere.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"
-#include <cstdlib>
 
 // ------------------------------------------------------------------------------------
 // moments helpers
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
                                                        size_t n, const T *__restrict__ stats) {
     const T sd = stats[0], r = stats[1];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        sm[i] = T(1) / (T(1) + exp(-sd * (ary[i] - r)));
+        sm[i] = sb_logistic_of_neg<T>(-sd * (ary[i] - r));
 }
 
 // ------------------------------------------------------------------------------------
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     // wave gets floor or ceil of nseg/W segments, and neighbouring waves read neighbouring memory
     const unsigned nwaves = gridDim.x * NWV;
     const size_t pl = (size_t)g.nx * g.ny;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && job.ticket) *job.ticket = 0;   // k_thc2's tile dealing starts over
+    if (blockIdx.x == 0 && threadIdx.x == 0 && job.ticket) *job.ticket = 0;   // spare device word, zeroed every call
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
     int cnt = 0;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
             const bool in = seg < nseg && X < g.nxh;
             const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
             const unsigned idx = in ? Yc * nxh + (unsigned)X : 0u;
-            t.mk[q] = job.mask[idx];
+            t.mk[q] = job.mask[job.mask_off + (in ? Yc * (unsigned)job.mask_ld + (unsigned)X : 0u)];
             t.sg[q] = T(0); t.ws[q] = T(0); t.wd[q] = T(0);
             if (do_stats) t.sg[q] = job.sigma[idx];                      // wave-uniform condition
             if (wrapper) {                                               // wave-uniform condition
@@ -282,115 +285,142 @@ __global__ __launch_bounds__(256) void k_t0(DiagJob<T> job) {
 }
 
 // ------------------------------------------------------------------------------------
-// Dense band-cell enumeration inside a workgroup: the workgroup covers 256 consecutive
-// longitudes of one latitude row; the band cells among them are compacted (ballot +
-// popcount prefix) so that thread i owns the i-th band cell.  Waves are full however
-// ragged the band is, surplus waves leave, and consecutive lanes still touch consecutive
-// longitudes inside a run.  Returns the number of band cells; s_x[i] is their longitude.
+// k_prep: the small jobs between k_scan and the kernels that consume its flags, one role per
+// workgroup (18 workgroups, ~2 us), so that neither the 256 persistent workgroups of k_thc3 nor
+// the waves of k_wind repeat them:
+//   block 0               k_scan's per-workgroup moments merged, in the fixed order and tree of
+//                         k_moments_final, into the sigmoid scalars (or published as this band's
+//                         moments for the multi-GPU gather)
+//   block 1               tile flags -> row-major list of active tiles: tile_list[0] = count
+//   blocks 2 .. 2+PARTS-1 band plane -> the 64-cell segments that hold band cells, each part a
+//                         contiguous range of segments with its own sub-list (ascending order)
 // ------------------------------------------------------------------------------------
-#define ROW_NT 256
+#define PREP_NT 1024
 
-// streaming load: non-temporal for data read once per call (the p columns; plain loads
-// measured 17 % slower for k_wind)
+// exclusive prefix of one int per thread over the workgroup; total in `total`.  Two barriers.
+__device__ __forceinline__ int block_excl_scan(int v, int *s_w, int &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int incl = sb_wave_scan_add(v);
+    __syncthreads();
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    const int wt = lane < PREP_NT / SB_WAVE ? s_w[lane] : 0;
+    const int wincl = sb_wave_scan_add(wt);
+    total = __shfl(wincl, PREP_NT / SB_WAVE - 1);
+    return incl - v + __shfl(wincl, wv) - __shfl(wt, wv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments *__restrict__ partials, int nparts,
+                                                  T *__restrict__ stats, Moments *__restrict__ moments_out) {
+    __shared__ Moments wpart[PREP_NT / SB_WAVE];
+    __shared__ int s_w[PREP_NT / SB_WAVE];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (nparts <= 0) return;
+        Moments m = moments_empty();
+        for (int b = tid; b < nparts; b += PREP_NT) m = moments_merge(m, partials[b]);
+        m = block_merge(m, wpart);
+        if (tid == 0) {
+            if (moments_out) *moments_out = m;
+            else sigmoid_scalars<T>(m, stats);
+        }
+        return;
+    }
+    if (blockIdx.x == 1) {
+        const int ntiles = job.thc_ntx * job.thc_nty;
+        const int per = (ntiles + PREP_NT - 1) / PREP_NT;
+        const int t0 = tid * per, t1 = min(t0 + per, ntiles);
+        int cnt = 0;
+        for (int t = t0; t < t1; ++t) cnt += job.tile_nnmax[t] != 0 ? 1 : 0;
+        int total;
+        int at = block_excl_scan(cnt, s_w, total);
+        for (int t = t0; t < t1; ++t)
+            if (job.tile_nnmax[t] != 0) job.tile_list[1 + at++] = t;
+        if (tid == 0) job.tile_list[0] = total;
+        return;
+    }
+    const int part = (int)blockIdx.x - 2;
+    const unsigned nseg = (unsigned)job.g.nyh * (unsigned)job.g.nw;
+    const unsigned cap = (unsigned)job.seg_cap;
+    const unsigned s0 = (unsigned)part * cap, s1 = min(s0 + cap, nseg);
+    const unsigned per = (cap + PREP_NT - 1) / PREP_NT;
+    const unsigned a0 = min(s0 + (unsigned)tid * per, s1), a1 = min(a0 + per, s1);
+    int cnt = 0;
+    for (unsigned sg = a0; sg < a1; ++sg) cnt += job.bandbits[sg] != 0 ? 1 : 0;
+    int total;
+    int at = block_excl_scan(cnt, s_w, total);
+    SbSegEntry *list = job.seg_list + (size_t)part * cap;
+    for (unsigned sg = a0; sg < a1; ++sg) {
+        const uint64_t w = job.bandbits[sg];
+        if (w) { SbSegEntry e; e.word = w; e.seg = sg; e.pad = 0; list[at++] = e; }
+    }
+    if (tid == 0) job.seg_count[part] = total;
+}
+
+// ------------------------------------------------------------------------------------
+// k_wind: level nearest the target pressure + wind speed/direction for every band cell, and -- on a
+// single domain, where k_thc3 has already left this call's contrast in thc -- thresholds, scaling and
+// state update.   ref: generic/sea_breeze_diag.f90:223-227,235-266; seabreeze_diag_python.f90:228-233
+// (1-D p: one level for all cells).
+//
+// Persistent waves work through k_prep's list of segments that hold band cells; a wave owns one aligned
+// 64-cell segment (four 128-byte lines of every level plane) at a time and its band lanes walk their p
+// column (nz planes, stride nx*ny) in whole batches of UN non-temporal loads.  No workgroup is launched
+// for the half of the 256-longitude row blocks that hold no band cell, no lane compaction, no barrier;
+// every line of p that holds a band cell is requested by exactly one wave.
+// ------------------------------------------------------------------------------------
+#define WIND_NT 256
+
 template <typename T, bool NTL>
 __device__ __forceinline__ T sb_ld(const T *p) {
     if constexpr (NTL) return __builtin_nontemporal_load(p);
     else return *p;
 }
 
-template <int CPW>
-__device__ __forceinline__ int block_band_cells(const uint64_t *__restrict__ bandbits, const Geo &g, int y,
-                                                unsigned short *s_x, int *s_wcnt) {
-    // the workgroup covers CPW * ROW_NT consecutive longitudes: CPW chunks of ROW_NT, a wave on 64 of them
-    constexpr int NW = ROW_NT / SB_WAVE;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    bool band[CPW];
-    uint64_t bm[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int x = (blockIdx.x * CPW + c) * ROW_NT + tid;
-        band[c] = x < g.nx && sb_bit(bandbits, g.nw, (x < g.nx ? x : 0) + g.h, y + g.h) != 0;
-        bm[c] = __ballot(band[c]);
-        if (lane == 0) s_wcnt[c * NW + wv] = __popcll(bm[c]);
-    }
-    __syncthreads();
-    int total = 0, before[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        before[c] = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const int cw = s_wcnt[c * NW + w];
-            before[c] += total * (w == 0 ? 1 : 0);               // entries of the chunks before this one
-            before[c] += (w < wv) ? cw : 0;
-            total += cw;
-        }
-    }
-    if (total == 0) return 0;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
-        if (band[c]) s_x[before[c] + __popcll(bm[c] & ((1ull << lane) - 1ull))] = (unsigned short)(c * ROW_NT + tid);
-    __syncthreads();
-    return total;
-}
-
-// ------------------------------------------------------------------------------------
-// k_wind: level nearest the target pressure + wind speed/direction for every band cell.
-// Band cells walk their p column (nz planes, stride nx*ny) with UN independent
-// non-temporal loads in flight and keep the first minimum of |p - target|
-// ref: generic/sea_breeze_diag.f90:223-227, seabreeze_diag_python.f90:228-233 (1-D p: one
-// level for all cells).  A workgroup covers CPW * 256 longitudes of one row: most row blocks hold
-// no band cell, and the launch of their waves is a measurable share of the kernel (14 us for the
-// empty grid at CPW = 1 on the 2560 x 1920 grid), so fewer, wider workgroups are launched.
-// ------------------------------------------------------------------------------------
-#ifndef SB_WIND_MINW
-#define SB_WIND_MINW 8               // waves per SIMD asked of the compiler for k_wind: 30 registers and 61 scalar
-#endif                               // registers per wave, so that eight 256-thread workgroups fit a CU
-#if SB_WIND_MINW > 0
-#define SB_WIND_BOUNDS __launch_bounds__(ROW_NT, SB_WIND_MINW)
-#else
-#define SB_WIND_BOUNDS __launch_bounds__(ROW_NT)
-#endif
-template <typename T, int UN, bool NTL, int CPW = 1>
-__global__ SB_WIND_BOUNDS void k_wind(DiagJob<T> job, int ystride, int early) {
-    __shared__ unsigned short s_x[ROW_NT * CPW];
-    __shared__ int s_wcnt[ROW_NT / SB_WAVE * CPW];
+template <typename T, int UN, bool FINAL>
+__global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T> job) {
     const Geo g = job.g;
-    // clear the other tile-flag buffer for the next call (this call's is read by k_thc)
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    for (int i = bid * ROW_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * gridDim.y * ROW_NT)
-        job.next_flags[i] = 0;
-    // row of this workgroup: with ystride S, consecutive blockIdx.y are rows/S apart (experiment)
-    int y = blockIdx.y;
-    if (ystride > 1) {
-        const int per = (g.rows + ystride - 1) / ystride;
-        y = ((int)blockIdx.y % ystride) * per + (int)blockIdx.y / ystride;
-        if (y >= g.rows) return;
-    }
-    if (early == 1) {
-        // no band cell among the longitudes: leave before any LDS traffic or barrier.  Every wave
-        // looks at the same words of the band plane, so the four waves agree.
-        const int X0 = blockIdx.x * ROW_NT * CPW + g.h, w0 = X0 >> 6;
-        const int lane = threadIdx.x & 63;
-        const int nwd = min(g.nw - w0, ROW_NT * CPW / 64 + ((X0 & 63) ? 1 : 0));
-        const uint64_t w = job.bandbits[(size_t)(y + g.h) * g.nw + w0 + (lane < nwd ? lane : 0)];
-        if (__ballot(lane < nwd && w != 0) == 0) return;
-    }
-    const int total = block_band_cells<CPW>(job.bandbits, g, y, s_x, s_wcnt);
-    if (early == 2) return;                                      // diagnostic: cost of the empty grid
+    const int lane = threadIdx.x & 63;
+    // clear the other tile-flag buffer for the next call (this call's was read by k_prep)
+    for (int i = blockIdx.x * WIND_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * WIND_NT) job.next_flags[i] = 0;
+    // the sub-lists' sizes -> position of an entry: lane k holds (count, inclusive prefix) of sub-list k
+    const int cnt = lane < SB_SEG_PARTS ? job.seg_count[lane] : 0;
+    const int incl = sb_wave_scan_add(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, SB_SEG_PARTS - 1);
+    const int nwaves = gridDim.x * (WIND_NT / SB_WAVE);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6));
+    auto entry = [&](int e) {
+        const uint64_t hit = __ballot(lane < SB_SEG_PARTS && e < incl);
+        const int part = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
+        const int base = __shfl(incl, part) - __shfl(cnt, part);
+        return job.seg_list[(size_t)part * job.seg_cap + (e < total ? e - base : 0)];
+    };
     const size_t pl = (size_t)g.nx * g.ny;
     const int nz = job.nz;
-    // one band cell per thread when the workgroup covers 256 longitudes: no loop.  With a loop the compiler
-    // keeps the constants of the fp64 atan2 / update below in registers across it: 93 registers per lane
-    // and 5 workgroups per CU instead of 8, which cost the kernel 5-10 us
-    for (int i = threadIdx.x; i < total; i += (CPW == 1 ? (1 << 30) : ROW_NT)) {
-        const int x = blockIdx.x * ROW_NT * CPW + s_x[i];
+    // 1-D p (f2py flavour): one level for the whole grid
+    int lev1 = 0;
+    if (job.flavour != SB_FLAVOUR_GENERIC) {
+        T best = fabs(job.p[0] - job.target_plev);
+        for (int k = 1; k < nz; ++k) {
+            const T a = fabs(job.p[k] - job.target_plev);
+            if (a < best) { best = a; lev1 = k; }
+        }
+    }
+    if (gw >= total) return;
+    SbSegEntry ent = entry(gw);
+    for (int e = gw; e < total; e += nwaves) {
+        const SbSegEntry cur = ent;
+        if (e + nwaves < total) ent = entry(e + nwaves);          // the next entry travels under this one's walk
+        const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
+        const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
+        if (!((cur.word >> lane) & 1ull)) continue;               // band bits are set for interior cells of processed rows only
         const size_t o = (size_t)y * g.nx + x;
         // the final update's inputs: issued ahead of the column walk
         T n_thc = T(0), ws_old = T(0), wd_old = T(0);
-        if (job.wind_final) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
-        int lev = 0;
-        if (job.flavour == SB_FLAVOUR_GENERIC) {
+        if constexpr (FINAL) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
+        int lev = lev1;
+        if (job.flavour == SB_FLAVOUR_GENERIC && job.level_rule == 0) {
             // whole batches of UN levels in flight; the last batch is padded by re-reading level
             // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
             // loads follows the batches
@@ -401,7 +431,7 @@ __global__ SB_WIND_BOUNDS void k_wind(DiagJob<T> job, int ystride, int early) {
 #pragma unroll
                 for (int q = 0; q < UN; ++q) {
                     const int k = k0 + q < nz ? k0 + q : nz - 1;
-                    d[q] = sb_ld<T, NTL>(pc + (size_t)k * pl);
+                    d[q] = sb_ld<T, true>(pc + (size_t)k * pl);
                 }
 #pragma unroll
                 for (int q = 0; q < UN; ++q) {
@@ -411,21 +441,40 @@ __global__ SB_WIND_BOUNDS void k_wind(DiagJob<T> job, int ystride, int early) {
                     else if (k < nz && a < best) { best = a; lev = k; }
                 }
             }
-        } else {
-            T best = fabs(job.p[0] - job.target_plev);
-            for (int k = 1; k < nz; ++k) {
-                const T a = fabs(job.p[k] - job.target_plev);
-                if (a < best) { best = a; lev = k; }
+        } else if (job.flavour == SB_FLAVOUR_GENERIC) {
+            // the UM copy's walk: upwards while |p - target| does not grow (ties move on), starting from a
+            // difference of 1e6; it stops at the first increase   ref: UM/vn10.7/sea_breeze_diag.F90:265-274.
+            // (Where even the first level is further than 1e6 from the target the UM copy leaves the level
+            // undefined; level 1 is used here.)
+            const T *pc = job.p + o;
+            T diff = T(1000000.);
+            bool done = false;
+            for (int k0 = 0; k0 < nz && !done; k0 += UN) {
+                T d[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q < nz ? k0 + q : nz - 1;
+                    d[q] = sb_ld<T, true>(pc + (size_t)k * pl);
+                }
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q;
+                    const T a = fabs(d[q] - job.target_plev);
+                    if (!done && k < nz) {
+                        if (a <= diff) { lev = k; diff = a; }
+                        else done = true;
+                    }
+                }
             }
         }
         const T uu = job.u[(size_t)lev * pl + o];
         const T vv = job.v[(size_t)lev * pl + o];
         const T n_ws = sqrt(uu * uu + vv * vv);                  // ref :225
         const T n_wd = atan2(-uu, -vv) * T(57.2957);             // ref :227, rad2deg (sic) :128
-        if (job.wind_final) {
-            // k_thc2 ran first and left this call's contrast in thc: thresholds, scaling and state
+        if constexpr (FINAL) {
+            // k_thc3 ran first and left this call's contrast in thc: thresholds, scaling and state
             // update happen here, under the HBM latency of the column walk   ref :235-266
-            sb_trigger_update<T>(job, o, n_thc, SbCellState<T>{n_ws, n_wd, ws_old, wd_old});
+            sb_trigger_update<T, false>(job, o, n_thc, SbCellState<T>{n_ws, n_wd, ws_old, wd_old});
         } else {
             job.nws[o] = n_ws;
             job.nwd[o] = n_wd;
@@ -469,90 +518,81 @@ static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool
 }
 
 template <typename T>
+static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
+    const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
+    if (job.wind_final) hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, true>), wg, wb, 0, st, job);
+    else hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, false>), wg, wb, 0, st, job);
+}
+
+// event pair k of a profiled call brackets kernel k (SB_PROF_*); pairs of kernels a call does not launch stay unrecorded
+#define SB_EV_BEGIN(k) do { if (ev) { (void)hipEventRecord(ev[2 * (k)], st); *lc.prof_mask |= 1u << (k); } } while (0)
+#define SB_EV_END(k)   do { if (ev) (void)hipEventRecord(ev[2 * (k) + 1], st); } while (0)
+
+template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     const Geo &g = job.g;
     hipStream_t st = lc.stream;
     hipEvent_t *ev = lc.prof;
-    static const int un = getenv("SB_WIND_UN") ? atoi(getenv("SB_WIND_UN")) : 8;   // tuning knob (diagnostic)
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
-    // k_thc2 merges k_scan's moments itself; the f2py flavour needs the scalars earlier, for k_t0
-    const bool merge_in_thc2 = job.t0_fly && !gathered;
     hipError_t e = hipSuccess;
     const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
     int nblk = (int)((nseg + 79) / 80);                          // 16 waves x 5 segments per trip
     if (nblk < 1) nblk = 1;
-    static const int scan_wgs = getenv("SB_SCAN_WGS") ? atoi(getenv("SB_SCAN_WGS")) : 1;   // tuning knob (diagnostic)
-    if (nblk > scan_wgs * lc.ncu) nblk = scan_wgs * lc.ncu;      // one 1024-thread workgroup per CU, two trips of loads in flight
-    // Single-domain calls on the k_thc2 path run the contrast first and let k_wind apply the
-    // thresholds and the state update (job.wind_final); a band step must run k_scan + k_wind
-    // before its ghost rows arrive, so there k_thc2 applies them.
-    if (job.wind_final && ph2) {
-        if (ev) { (void)hipEventRecord(ev[0], st); }
+    if (nblk > lc.ncu) nblk = lc.ncu;                            // one 1024-thread workgroup per CU, two trips of loads in flight
+    const dim3 pg(2 + SB_SEG_PARTS), pb(PREP_NT);
+    // Single-domain calls run the contrast first and let k_wind apply the thresholds and the state update
+    // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there k_thc3
+    // applies them.
+    if (job.wind_final && ph1 && ph2) {
+        SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, true, st);
-        if (!merge_in_thc2)
-            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
-                               (Moments *)nullptr);
-        if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[4], st); }
-        if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-        if (ev) { (void)hipEventRecord(ev[5], st); }
-        if ((e = sb_launch_thc2<T>(job, H, lc.ncu, merge_in_thc2 ? lc.partials : nullptr, merge_in_thc2 ? nblk : 0,
-                                   (T *)lc.stats, st)) != hipSuccess) return e;
-        if (ev) { (void)hipEventRecord(ev[6], st); (void)hipEventRecord(ev[7], st); (void)hipEventRecord(ev[2], st); }
-        static const int ystr = getenv("SB_WIND_YSTRIDE") ? atoi(getenv("SB_WIND_YSTRIDE")) : 1;   // tuning knob (diagnostic)
-        static const int early = getenv("SB_WIND_EARLY") ? atoi(getenv("SB_WIND_EARLY")) : 0;       // tuning knob (diagnostic)
-        const int gy = ystr > 1 ? ystr * ((g.rows + ystr - 1) / ystr) : g.rows;
-        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, gy), wb(ROW_NT);
-        if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, ystr, early);
-        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, ystr, early);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, ystr, early);
-        if (ev) { (void)hipEventRecord(ev[3], st); }
+        SB_EV_END(SB_PROF_SCAN);
+        SB_EV_BEGIN(SB_PROF_PREP);
+        hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, nblk, (T *)lc.stats, (Moments *)nullptr);
+        SB_EV_END(SB_PROF_PREP);
+        if (!job.t0_fly) {
+            SB_EV_BEGIN(SB_PROF_T0);
+            hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+            SB_EV_END(SB_PROF_T0);
+        }
+        SB_EV_BEGIN(SB_PROF_THC);
+        if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+        SB_EV_END(SB_PROF_THC);
+        SB_EV_BEGIN(SB_PROF_WIND);
+        launch_wind<T>(job, lc.ncu, st);
+        SB_EV_END(SB_PROF_WIND);
         return hipGetLastError();
     }
-    // ---- phase 1: needs neither theta's ghost cells nor the statistics -----------------------
+    // ---- phase 1: needs neither theta's ghost cells nor the statistics of the other bands ---------
     if (ph1) {
-        // k_scan (+ merge of the statistics when they are this domain's own and k_thc2 does not do it)
-        if (ev) (void)hipEventRecord(ev[0], st);
         // a band step takes this band's own sigma moments from the same pass (lc.moments_out), publishes
         // them for the all-gather and signals the communication stream
-        launch_scan<T>(job, nblk, lc.partials, !gathered || lc.moments_out != nullptr, st);
-        if (gathered && lc.moments_out) {
-            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
-                               lc.moments_out);
-            if (lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
-        }
-        if (!gathered && !merge_in_thc2)
-            hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, lc.partials, nblk, (T *)lc.stats,
-                               (Moments *)nullptr);
-        if (ev) (void)hipEventRecord(ev[1], st);
-        // k_wind
-        if (ev) (void)hipEventRecord(ev[2], st);
-        const dim3 wg((g.nx + ROW_NT - 1) / ROW_NT, g.rows), wb(ROW_NT);
-        static const bool plain = getenv("SB_WIND_PLAIN") != nullptr;   // tuning knob (diagnostic)
-        if (plain) hipLaunchKernelGGL((k_wind<T, 8, false>), wg, wb, 0, st, job, 1, 0);
-        else if (un <= 4) hipLaunchKernelGGL((k_wind<T, 4, true>), wg, wb, 0, st, job, 1, 0);
-        else if (un <= 8) hipLaunchKernelGGL((k_wind<T, 8, true>), wg, wb, 0, st, job, 1, 0);
-        else hipLaunchKernelGGL((k_wind<T, 14, true>), wg, wb, 0, st, job, 1, 0);
-        if (ev) (void)hipEventRecord(ev[3], st);
+        const bool own_stats = !gathered || lc.moments_out != nullptr;
+        SB_EV_BEGIN(SB_PROF_SCAN);
+        launch_scan<T>(job, nblk, lc.partials, own_stats, st);
+        SB_EV_END(SB_PROF_SCAN);
+        SB_EV_BEGIN(SB_PROF_PREP);
+        hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats ? nblk : 0, (T *)lc.stats,
+                           gathered ? lc.moments_out : (Moments *)nullptr);
+        SB_EV_END(SB_PROF_PREP);
+        if (gathered && lc.moments_out && lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
+        SB_EV_BEGIN(SB_PROF_WIND);
+        launch_wind<T>(job, lc.ncu, st);
+        SB_EV_END(SB_PROF_WIND);
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
-        // the bands' moments: merged by k_thc2 itself (host-model flavour, up to 64 bands: the same tree as
-        // k_merge_moments) or by a launch of their own (the f2py flavour's k_t0 needs the scalars first)
-        const bool gath_in_thc2 = gathered && job.t0_fly && lc.ngathered <= SB_WAVE;
-        if (gathered && !gath_in_thc2)
+        if (gathered)
             hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered, (T *)lc.stats);
-        if (ev) (void)hipEventRecord(ev[4], st);
-        // k_t0 (f2py flavour: the t0 plane is an output)
-        if (!job.t0_fly) hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
-        if (ev) (void)hipEventRecord(ev[5], st);
-        // contrast, thresholds, state update
-        const Moments *mp = merge_in_thc2 ? lc.partials : gath_in_thc2 ? lc.gathered : nullptr;
-        const int mn = merge_in_thc2 ? nblk : gath_in_thc2 ? lc.ngathered : 0;
-        e = sb_launch_thc2<T>(job, H, lc.ncu, mp, mn, (T *)lc.stats, st);
-        if (e != hipSuccess) return e;
-        if (ev) (void)hipEventRecord(ev[6], st);
-        if (ev) (void)hipEventRecord(ev[7], st);
+        if (!job.t0_fly) {
+            SB_EV_BEGIN(SB_PROF_T0);
+            hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
+            SB_EV_END(SB_PROF_T0);
+        }
+        SB_EV_BEGIN(SB_PROF_THC);
+        if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+        SB_EV_END(SB_PROF_THC);
     }
     return hipGetLastError();
 }

@@ -3,24 +3,35 @@
 #include "sb_device.hpp"
 
 #define SB_STATS_MAX_BLOCKS 2048
-#define SB_MAX_LDS_HALO 32          // largest LDS halo a contrast kernel is instantiated for (k_thc2; 24: k_thc)
-#define SB_DIST_TY 4                 // rows per k_dist tile
-#define SB_PROF_EVENTS 8            // events one profiled diag call records
-#define SB_PROF_KERNELS 5           // k_scan, k_wind, k_t0, k_thc2, (unused)
+#define SB_MAX_LDS_HALO 32          // largest LDS halo the contrast kernel (k_thc3) is instantiated for
+#define SB_DIST_TY 4                // rows per k_dist tile
+// kernels of a diag call that sb_profile_begin / sb_profile_end time, each with its own pair of events
+enum { SB_PROF_SCAN = 0, SB_PROF_WIND = 1, SB_PROF_T0 = 2, SB_PROF_THC = 3, SB_PROF_PREP = 4, SB_PROF_KERNELS = 5 };
+#define SB_PROF_EVENTS (2 * SB_PROF_KERNELS)
+#ifndef SB_WIND_UN
+#define SB_WIND_UN 8                // levels of a p column in flight per lane of k_wind
+#endif
+#ifndef SB_WIND_WGS_PER_CU
+#define SB_WIND_WGS_PER_CU 4        // persistent 256-thread workgroups of k_wind per compute unit (= its waves per SIMD:
+                                    // the gather is bound by the memory system from two workgroups per CU upwards,
+                                    // tools/probe_gather.hip, and 128 registers keep the update code free of spills)
+#endif
 
 // Everything of the context a diag launch needs besides the job itself.
 struct SbLaunchCtx {
     hipStream_t stream;             // every kernel of the call is enqueued here
     hipEvent_t *prof;               // SB_PROF_EVENTS timing events of this call, or nullptr
+    unsigned *prof_mask;            // bit k set: kernel k was launched (and its event pair recorded) in this call
     Moments *partials;              // per-workgroup reduction partials
     void *stats;                    // sigmoid scalars (4 x T)
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
-    Moments *moments_out;           // band step: k_scan's own moments go here (k_moments_final) ...
+    Moments *moments_out;           // band step: k_scan's own moments go here (k_prep) ...
     hipEvent_t moments_event;       // ... and this event is recorded behind them, or nullptr
-    int ncu;                        // compute units (k_scan / k_thc run one workgroup per CU)
-    int phases;                     // bit 0: k_scan + k_wind (no ghost cells, no statistics needed);
-                                    // bit 1: statistics merge, k_t0, k_thc2.  3 = the whole call
+    int ncu;                        // compute units (k_scan / k_thc3 run one workgroup per CU)
+    int thc_nt;                     // threads of a k_thc3 workgroup: 512 or 1024
+    int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
+                                    // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
 };
 
 template <typename T>
@@ -30,11 +41,11 @@ template <typename T>
 hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats, hipStream_t st);
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
-void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);         // tile size of the contrast kernel that will run                                         // k_thc tiles are 64 x this many cells
-// the fused second half (H <= 16): partials/nparts: k_scan's moments to merge (0: read job.stats)
+// tile size of the contrast kernel that will run for an LDS halo of H cells
+void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);
+// the contrast kernel: reads the list of active tiles and the sigmoid scalars k_prep left
 template <typename T>
-hipError_t sb_launch_thc2(const DiagJob<T> &job, int H, int ncu, const Moments *partials, int nparts, T *stats_out,
-                          hipStream_t st);
+hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStream_t st);   // nt: 512 or 1024 threads
 
 template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st);

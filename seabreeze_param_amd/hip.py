@@ -100,6 +100,10 @@ class Context:
         """0: automatic, 32 / 48 / 64: force the contrast kernel's tile height (tuning / test knob)."""
         self._chk(self.lib.sb_set_tile_rows(self.h, C.c_int(rows)), "sb_set_tile_rows")
 
+    def set_thc_threads(self, threads: int):
+        """512 or 1024 threads per contrast-kernel workgroup (tuning / test knob)."""
+        self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
+
     def last_counters(self):
         arr = (C.c_longlong * 4)()
         self._chk(self.lib.sb_last_counters(self.h, arr), "sb_last_counters")
@@ -109,14 +113,13 @@ class Context:
         self._chk(self.lib.sb_profile_begin(self.h, C.c_int(max_calls)), "sb_profile_begin")
 
     def profile_end(self):
-        """-> ({'k_scan', 'k_wind', 'k_gz', 'k_thc', 'k_final'} -> ms, ncalls): HIP-event averages of the
-        launches of one diag call.  k_thc is k_thc2 (moments merge, t0, tables, search) on the default
-        path; k_gz is k_t0 for the f2py flavour and empty for the host-model flavour (k_thc2 forms t0
-        itself); k_scan includes k_moments_final where that is still a launch; k_final is unused."""
+        """-> ({'k_scan', 'k_wind', 'k_t0', 'k_thc', 'k_prep'} -> ms, ncalls): HIP-event averages of the
+        launches of one diag call.  k_thc is k_thc3 (t0, tables, search); k_t0 exists for the f2py flavour
+        only (0.0 where a call does not launch it); k_prep is the list / statistics kernel after k_scan."""
         ms = (C.c_double * 5)()
         n = C.c_int(0)
         self._chk(self.lib.sb_profile_end(self.h, ms, C.byref(n)), "sb_profile_end")
-        return dict(k_scan=ms[0], k_wind=ms[1], k_gz=ms[2], k_thc=ms[3], k_final=ms[4]), n.value
+        return dict(k_scan=ms[0], k_wind=ms[1], k_t0=ms[2], k_thc=ms[3], k_prep=ms[4]), n.value
 
     # ------------------------------------------------------------------ host-pointer API
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
@@ -206,6 +209,20 @@ class Context:
                 C.c_void_p(stream) if stream else None)
         self._chk(rc, "sb_seabreeze_diag_dev")
 
+
+    def get_edges_dev(self, dtype, nx, ny, lsm, ci, coast, rule=0, bnd=SB_BND_WRAPPER, stream=None):
+        """get_edges on device arrays (raw addresses); enqueues without synchronising."""
+        fn = getattr(self.lib, f"sb_get_edges_{_SFX[np.dtype(dtype)]}_dev")
+        self._chk(fn(self.h, C.c_int(nx), C.c_int(ny), _p(lsm), _p(ci), C.c_int(rule), C.c_int(bnd), _p(coast),
+                     C.c_void_p(stream) if stream else None), "sb_get_edges_dev")
+
+    def get_dist_dev(self, dtype, nx, ny, coast, mask, lon, lat, cdist, maxdist=180.0, kwin=-1, stream=None):
+        """get_dist on device arrays (raw addresses); lon, lat are host vectors."""
+        dt = np.dtype(dtype)
+        lon = _host(lon, dt); lat = _host(lat, dt)
+        fn = getattr(self.lib, f"sb_get_dist_{_SFX[dt]}_dev")
+        self._chk(fn(self.h, C.c_int(nx), C.c_int(ny), _p(coast), _p(mask), _p(lon), _p(lat), _CT[dt](maxdist),
+                     C.c_int(kwin), _p(cdist), C.c_void_p(stream) if stream else None), "sb_get_dist_dev")
 
     def sigma_moments_dev(self, dtype, nx, ny, halo, sigma, moments5, stream=None):
         """Band-local sigma moments -> 5 doubles at device address moments5."""

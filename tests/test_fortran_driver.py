@@ -1,4 +1,4 @@
-"""The Fortran host side: fortran/sea_breeze_diag_mod.F90 + halo_exchange_mod.f90 driven by
+"""The Fortran host side: fortran/sea_breeze_diag_mod.F90 + halo_exchange_mod.F90 + sb_context_mod.F90 driven by
 fortran/dummy_model.f90 in the reference's own call order (generic/dummy_model.f90:27-55).
 
 BASELINE.json configs[0]: 96x72 synthetic coastline through the Fortran surface.
@@ -81,3 +81,74 @@ def test_dummy_model_matches_oracle(tmp_path, oracles, prec):
             assert np.max(np.abs(thc - state[2])) < 2e-3
             near = np.abs(np.abs(state[2]) - 0.75) < 5e-3
             assert np.max(np.abs(sb - state[3])[~near]) < 5e-3
+
+
+def _oracle_sequence(orc, st, p, steps, cdist, prec):
+    dt = np.float64 if prec == 8 else np.float32
+    ny, nx = st.ny, st.nx
+    so = [np.zeros((ny, nx), dt) for _ in range(4)]
+    out = []
+    for t, (th, u, v) in enumerate(steps, start=1):
+        orc.seabreeze_diag(1440.0, t, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+        out.append([a.copy() for a in so])
+    return out
+
+
+def _check_against_oracle(raw, per, ref, prec, rows=slice(None)):
+    """raw: the per-step part of output.bin (sb_con, ws, wd, thc per step); ref: oracle states (ws, wd, thc, sb_con)"""
+    for t, so in enumerate(ref):
+        blk = raw[t * 4 * per:(t + 1) * 4 * per]
+        sb, ws, wd, thc = (blk[i * per:(i + 1) * per].reshape(so[0][rows].shape) for i in range(4))
+        if prec == 8:
+            for a, b, nm in ((ws, so[0], "ws"), (wd, so[1], "wd"), (thc, so[2], "thc"), (sb, so[3], "sb_con")):
+                assert relerr(a, b[rows], floor=1e-2) < 1e-7, (t + 1, nm)
+            assert np.array_equal(sb != 0, so[3][rows] != 0)
+        else:
+            assert relerr(ws, so[0][rows], floor=1e-3) < 2e-6 and relerr(wd, so[1][rows], floor=1e-1) < 2e-5
+            assert np.max(np.abs(thc - so[2][rows])) < 2e-3
+            near = np.abs(np.abs(so[2][rows]) - 0.75) < 5e-3
+            assert np.max(np.abs(sb[~near] - so[3][rows][~near])) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [8, 4])
+def test_dummy_model_device_resident_mode(tmp_path, oracles, prec):
+    """`dummy_model ... dev`: the Fortran host keeps every field on the device (sb_dev_alloc / sb_dev_upload of
+    sb_context_mod) and calls seabreeze_diag_dev -- the surface a GPU-resident host model uses."""
+    assert _built()
+    nx, ny, nz, halo, nsteps = 96, 72, 5, 4, 3
+    dt = np.float64 if prec == 8 else np.float32
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    st, p, steps = _write_input(fin, prec, nx, ny, nz, halo, nsteps)
+    r = subprocess.run([EXE[prec], str(fin), str(fout), str(nsteps), "dev"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(fout, dtype=dt)
+    n2 = nx * ny
+    orc = oracles[prec]
+    coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=halo)
+    assert relerr(raw[:n2].reshape(ny, nx), cdist) < (1e-9 if prec == 8 else 2e-6)
+    _check_against_oracle(raw[n2:], n2, _oracle_sequence(orc, st, p, steps, raw[:n2].reshape(ny, nx), prec), prec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [8, 4])
+def test_dummy_model_band_mode_one_rank_communicator(tmp_path, oracles, prec):
+    """`dummy_model ... band 0 1 <idfile>`: the Fortran host initialises the library's RCCL communicator
+    (sb_comm_get_unique_id / sb_comm_init through sb_context_mod), fills the static fields' ghost cells through
+    halo_exchange_mod::swap_bounds -> sb_swap_bounds_* and steps with band_seabreeze_diag.  One rank is what a
+    one-GPU box can run: the band is the globe, its ghost rows replicate the pole rows, and the result must equal
+    the single-domain oracle.  (Two and three bands: tests/test_bands_gloo.py, tests/test_bands_gpu.py.)"""
+    assert _built()
+    nx, ny, nz, halo, nsteps = 96, 72, 4, 5, 3
+    dt = np.float64 if prec == 8 else np.float32
+    fin, fout, idf = tmp_path / "in.bin", tmp_path / "out.bin", tmp_path / "rccl.id"
+    st, p, steps = _write_input(fin, prec, nx, ny, nz, halo, nsteps)
+    r = subprocess.run([EXE[prec], str(fin), str(fout), str(nsteps), "band", "0", "1", str(idf)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert idf.exists() and idf.stat().st_size == 128
+    raw = np.fromfile(fout, dtype=dt)
+    n2 = nx * ny
+    orc = oracles[prec]
+    _check_against_oracle(raw[n2:], n2, _oracle_sequence(orc, st, p, steps, raw[:n2].reshape(ny, nx), prec), prec)
