@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from seabreeze_param_amd import hip, synth  # noqa: E402
-from seabreeze_param_amd.bands import BandRunner, split_rows  # noqa: E402
+from seabreeze_param_amd.bands import BandRunner, row_cost, split_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REL_FLOOR = 1e-2        # parity: |a-b| / max(|b|, REL_FLOOR)
@@ -253,7 +253,9 @@ def main():
     kwin = hip.dist_window(st.lon, st.lat)
     band = np.abs(cdist) <= 180.0
     n_band_total = int(band.sum())
-    r0, r1 = split_rows(ny, world)[rank]
+    # bands cut by cost (5 units per cell + nz+7 per coastal-band cell), not by row count: the band is clustered
+    # in latitude; every rank derives the same cuts from the same distance field
+    r0, r1 = split_rows(ny, world, cost=row_cost(band, nz) if world > 1 else None, min_rows=kwin + 1)[rank]
     rows = (r0, r1)                      # every rank generates only its own band of the 3-D fields
     p_full = synth.pressure_3d(st, nz, dt, rows=rows)
     theta_a = synth.theta_step(st, 1, dt)
@@ -262,7 +264,7 @@ def main():
     gen_s = time.perf_counter() - t_gen
 
     runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1, dtype=dt,
-                        comm=comm if world > 1 else "torch")
+                        comm=comm if world > 1 else "torch", rows=rows)
     runner.upload_static(st.z, st.sigma, cdist)
     # two input sets at different addresses: B swaps u and v (distinct synthetic winds) and
     # uses the next step's theta, so no step re-reads the lines the previous one fetched

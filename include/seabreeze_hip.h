@@ -142,6 +142,49 @@ int sb_seabreeze_diag_f32_dev(sb_ctx *ctx, float timestep_s, int timestep_number
                           void *stream);
 
 /* -------------------------------------------------------------------------------- */
+/* seabreeze_diag -- UM vn10.7 field layout                                          */
+/* replaces: subroutine seabreeze_diag(timestep, timestep_number, p, u, v, theta, z, */
+/*           sigma, mask, windspeed, winddir, thc, sb_con, error)                    */
+/*           ref: UM/vn10.7/sea_breeze_diag.F90:55-56 (argument order), :66-117      */
+/*           (bounds), :198-202 (error), :210-211 (theta <- t0), :265-274 (level)    */
+/* p, u, v, sb_con on pdims and windspeed, winddir, thc on tdims: (nx,ny[,nz]), no    */
+/* ghost cells.  theta, z, sigma on tdims_s: (nx+2*halo_s, ny+2*halo_s).  mask (the   */
+/* signed coast distance) on tdims_l: (nx+2*halo_l, ny+2*halo_l), halo_l >= halo_s.   */
+/* The window reads both t0 and mask, so it can use halo_s ghost cells; a cell whose  */
+/* window would need more yields NaN and is counted (sb_last_counters [2]).           */
+/* *error = 1 and nothing done when ny < 1 or nz < 1 (UM :198-202), else 0.           */
+/* flags: SB_UM_THETA_TO_T0 -- theta comes back as t0 = theta - gmma*z*sigmoid(sigma), */
+/*        ghost cells included (UM :210-211; the arithmetic does not depend on it);    */
+/*        SB_UM_LEVEL_WALK -- the UM copy's level rule: upwards from level 1 while     */
+/*        |p - 70000| does not grow (ties move on), stop at the first increase         */
+/*        (:265-274), instead of the generic file's first minimum over all levels.     */
+/* The UM file cannot be compiled outside the UM: this entry point    */
+/* follows its text; parity is pinned only through the generic/wrapper arithmetic.     */
+/* -------------------------------------------------------------------------------- */
+#define SB_UM_THETA_TO_T0 1
+#define SB_UM_LEVEL_WALK  2
+int sb_seabreeze_diag_um_f64(sb_ctx *ctx, double timestep_s, int timestep_number, int nx, int ny, int nz,
+                             int halo_s, int halo_l, const double *p, const double *u, const double *v,
+                             double *theta, const double *z, const double *sigma, const double *mask,
+                             double *windspeed, double *winddir, double *thc, double *sb_con, int flags,
+                             int *error);
+int sb_seabreeze_diag_um_f32(sb_ctx *ctx, float timestep_s, int timestep_number, int nx, int ny, int nz,
+                             int halo_s, int halo_l, const float *p, const float *u, const float *v,
+                             float *theta, const float *z, const float *sigma, const float *mask,
+                             float *windspeed, float *winddir, float *thc, float *sb_con, int flags,
+                             int *error);
+int sb_seabreeze_diag_um_f64_dev(sb_ctx *ctx, double timestep_s, int timestep_number, int nx, int ny, int nz,
+                             int halo_s, int halo_l, const double *p, const double *u, const double *v,
+                             double *theta, const double *z, const double *sigma, const double *mask,
+                             double *windspeed, double *winddir, double *thc, double *sb_con, int flags,
+                             int *error, void *stream);
+int sb_seabreeze_diag_um_f32_dev(sb_ctx *ctx, float timestep_s, int timestep_number, int nx, int ny, int nz,
+                             int halo_s, int halo_l, const float *p, const float *u, const float *v,
+                             float *theta, const float *z, const float *sigma, const float *mask,
+                             float *windspeed, float *winddir, float *thc, float *sb_con, int flags,
+                             int *error, void *stream);
+
+/* -------------------------------------------------------------------------------- */
 /* diag -- f2py-surface flavour (whole global grid, 1-D p, packed output)            */
 /* replaces: subroutine diag(timestep_number, p, z, std, theta, v, u, cdist,         */
 /*           windspeed, winddir, thc, target_plev, thresh_wind, thresh_winddir,      */
@@ -182,6 +225,41 @@ int sb_diag_f32_dev(sb_ctx *ctx, int timestep_number, const float *p, const floa
                 float thresh_windch, float thresh_thc, float target_time,
                 float maxdist, float timestep, int nps, int nlons, int nlats,
                 float *output, void *stream);
+
+/* -------------------------------------------------------------------------------- */
+/* diag, streamed: many timesteps on one grid                */
+/* replaces: the per-timestep loop of the reference's Python driver,                 */
+/*           ref: python_wrapper/seabreezediag/__init__.py:222-245 -- every step it   */
+/*           hands diag the same z, std, cdist and the state of the step before.      */
+/* sb_diag_stream_begin uploads those six planes once; sb_diag_stream_step takes one  */
+/* step's p(nps), theta(nlons,nlats), v, u (nlons,nlats,nps) -- host pointers, units  */
+/* and tunables as sb_diag_* -- uploads theta and the one u, v plane p selects through */
+/* pinned double-buffered staging and enqueues the step; it hands back the sb_con     */
+/* plane of the PREVIOUS step (rows 1..nlats-1 of sb_con_prev, as double, what the    */
+/* reference's driver accumulates; *have_prev = 0 on the first step), so that staging  */
+/* step i+1 overlaps the device work of step i.  sb_diag_stream_end waits, returns the */
+/* last step's sb_con, the last step's four output planes and the final state (any of  */
+/* them may be NULL).  Results are those of sb_diag_* called step by step.             */
+/* sb_diag_stream_stats: steps so far and where the host spent its time, in seconds:   */
+/* [0] host copies (staging, sb_con out) [1] enqueueing [2] waiting for the device.    */
+/* -------------------------------------------------------------------------------- */
+int sb_diag_stream_begin_f32(sb_ctx *ctx, int nlons, int nlats, const float *z, const float *std,
+                             const float *cdist, const float *windspeed, const float *winddir, const float *thc);
+int sb_diag_stream_begin_f64(sb_ctx *ctx, int nlons, int nlats, const double *z, const double *std,
+                             const double *cdist, const double *windspeed, const double *winddir, const double *thc);
+int sb_diag_stream_step_f32(sb_ctx *ctx, int timestep_number, const float *p, int nps, const float *theta,
+                            const float *v, const float *u, float target_plev, float thresh_wind,
+                            float thresh_winddir, float thresh_windch, float thresh_thc, float target_time,
+                            float maxdist, float timestep, double *sb_con_prev, int *have_prev);
+int sb_diag_stream_step_f64(sb_ctx *ctx, int timestep_number, const double *p, int nps, const double *theta,
+                            const double *v, const double *u, double target_plev, double thresh_wind,
+                            double thresh_winddir, double thresh_windch, double thresh_thc, double target_time,
+                            double maxdist, double timestep, double *sb_con_prev, int *have_prev);
+int sb_diag_stream_end_f32(sb_ctx *ctx, double *sb_con_last, float *output4, float *windspeed, float *winddir,
+                           float *thc);
+int sb_diag_stream_end_f64(sb_ctx *ctx, double *sb_con_last, double *output4, double *windspeed, double *winddir,
+                           double *thc);
+int sb_diag_stream_stats(sb_ctx *ctx, long *steps, double seconds[3]);
 
 /* -------------------------------------------------------------------------------- */
 /* sigmoid                                                                           */

@@ -116,7 +116,7 @@ class Oracle:
         return sd.value, r.value
 
     def seabreeze_diag(self, timestep, tn, p, u, v, theta, mask, z, sigma, ws, wd, thc, sb_con,
-                       halo=0, bnd=1, omp=False, ext_stats=None):
+                       halo=0, bnd=1, omp=False, ext_stats=None, level_rule=0):
         dt, ct = self.dt, self.ct
         p = _f(p, dt); u = _f(u, dt); v = _f(v, dt)
         theta = _f(theta, dt); mask = _f(mask, dt); z = _f(z, dt); sigma = _f(sigma, dt)
@@ -138,7 +138,7 @@ class Oracle:
             ct(timestep), C.c_int(tn), _ptr(p), _ptr(u), _ptr(v), _ptr(theta), _ptr(mask),
             _ptr(z), _ptr(sigma), _ptr(ws), _ptr(wd), _ptr(thc), _ptr(sb_con),
             C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo), C.c_int(bnd),
-            C.c_int(use_ext), ct(es), ct(er), C.byref(nn))
+            C.c_int(use_ext), ct(es), ct(er), C.c_int(level_rule), C.byref(nn))
         self.last_nn_max = nn.value
         return sb_con
 

@@ -253,7 +253,7 @@ contains
     real, intent(inout) :: thc(nlons,nlats), sb_con(nlons,nlats)
     integer(c_int), intent(out) :: nn_max
     call sbo_seabreeze_diag_x(timestep, tn, p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con, &
-                              nlons, nlats, nz, h, bnd, 0, 0., 0., nn_max)
+                              nlons, nlats, nz, h, bnd, 0, 0., 0., 0, nn_max)
   end subroutine sbo_seabreeze_diag
 
   ! scalars of the logistic (std, r) for a field, ref: generic/sea_breeze_diag.f90:466-479
@@ -277,12 +277,16 @@ contains
   ! As sbo_seabreeze_diag; with use_ext /= 0 the logistic scalars come from the caller
   ! (the GLOBAL field's std and r) instead of this sub-domain's sigma: what one latitude
   ! band of a decomposed grid has to use to reproduce the single-domain result.
+  ! level_rule 0: first minimum of |p - target| over all levels (ref: generic/sea_breeze_diag.f90:223);
+  ! level_rule 1: the UM copy's walk -- upwards from level 1 while the difference does not grow, starting from
+  ! 1000000., stop at the first increase (ref: UM/vn10.7/sea_breeze_diag.F90:265-274; where even level 1 fails
+  ! the UM copy leaves p_lev undefined, level 1 is used here).
   subroutine sbo_seabreeze_diag_x(timestep, tn, p, u, v, theta, mask, z, sigma, &
                                 windspeed, winddir, thc, sb_con, &
-                                nlons, nlats, nz, h, bnd, use_ext, ext_std, ext_r, nn_max) &
+                                nlons, nlats, nz, h, bnd, use_ext, ext_std, ext_r, level_rule, nn_max) &
       bind(C, name='sbo_seabreeze_diag_x')
     real, value, intent(in) :: timestep, ext_std, ext_r
-    integer(c_int), value, intent(in) :: tn, nlons, nlats, nz, h, bnd, use_ext
+    integer(c_int), value, intent(in) :: tn, nlons, nlats, nz, h, bnd, use_ext, level_rule
     real, intent(in) :: p(nlons,nlats,nz), u(nlons,nlats,nz), v(nlons,nlats,nz)
     real, intent(in) :: theta(1-h:nlons+h,1-h:nlats+h), mask(1-h:nlons+h,1-h:nlats+h)
     real, intent(in) :: z(1-h:nlons+h,1-h:nlats+h), sigma(1-h:nlons+h,1-h:nlats+h)
@@ -293,8 +297,8 @@ contains
     real, parameter :: thresh_windch = 5., thresh_thc = 0.75, target_time = 6.*60**2
     real, parameter :: maxdist = 180.
     real, allocatable :: t0(:,:), s_in(:,:), s_sm(:,:)
-    real :: mean, var, std, r, n_thc, n_ws, n_wd
-    integer :: i, j, lev, nn
+    real :: mean, var, std, r, n_thc, n_ws, n_wd, p_lev_diff
+    integer :: i, j, lev, nn, k
     logical :: refresh
 
     allocate(t0(1-h:nlons+h,1-h:nlats+h))
@@ -326,7 +330,20 @@ contains
         else
           call contrast(j, i, mask, t0, nlons, nlats, h, bnd, nlons+nlats, n_thc, nn)
           nn_max = max(nn_max, nn)
-          lev = int(minloc(abs(p(j,i,:) - target_plev), 1))   ! ref :223
+          if (level_rule == 0) then
+            lev = int(minloc(abs(p(j,i,:) - target_plev), 1))   ! ref :223
+          else
+            p_lev_diff = 1000000.                               ! ref: UM/vn10.7/sea_breeze_diag.F90:265-274
+            lev = 1
+            do k = 1, nz
+              if (abs(p(j,i,k) - target_plev) <= p_lev_diff) then
+                lev = k
+                p_lev_diff = abs(p(j,i,k) - target_plev)
+              else
+                exit
+              end if
+            end do
+          end if
           n_ws = sqrt(u(j,i,lev)**2 + v(j,i,lev)**2)
           n_wd = atan2(-1*u(j,i,lev), -1*v(j,i,lev)) * c_rad2deg
           if (tn < 2) then

@@ -9,6 +9,10 @@ module sb_f2py_state
   use iso_c_binding
   implicit none
   type(c_ptr), save :: ctx = c_null_ptr
+  ! status of the last routine of the surface: 0, or the library's sb_status with its message.  The reference
+  ! kernels have no error channel here; the Python layer reads these after every call and raises.
+  integer(c_int), save :: last_rc = 0
+  character(len=512), save :: last_msg = ''
 
   interface
     integer(c_int) function sb_create(ctx, device) bind(C, name="sb_create")
@@ -34,6 +38,38 @@ module sb_f2py_state
       real(c_float), value :: target_time, maxdist, timestep
       real(c_float), intent(in) :: p(*), z(*), std(*), theta(*), v(*), u(*), cdist(*)
       real(c_float), intent(inout) :: ws(*), wd(*), thc(*), output(*)
+    end function
+    integer(c_int) function sb_diag_stream_begin_f32(ctx, nlons, nlats, z, std, cdist, ws, wd, thc) &
+        bind(C, name="sb_diag_stream_begin_f32")
+      import :: c_ptr, c_int, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nlons, nlats
+      real(c_float), intent(in) :: z(*), std(*), cdist(*), ws(*), wd(*), thc(*)
+    end function
+    integer(c_int) function sb_diag_stream_step_f32(ctx, tn, p, nps, theta, v, u, target_plev, thresh_wind, &
+        thresh_winddir, thresh_windch, thresh_thc, target_time, maxdist, timestep, sb_prev, have_prev) &
+        bind(C, name="sb_diag_stream_step_f32")
+      import :: c_ptr, c_int, c_float, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: tn, nps
+      real(c_float), value :: target_plev, thresh_wind, thresh_winddir, thresh_windch, thresh_thc
+      real(c_float), value :: target_time, maxdist, timestep
+      real(c_float), intent(in) :: p(*), theta(*), v(*), u(*)
+      real(c_double), intent(inout) :: sb_prev(*)
+      integer(c_int), intent(out) :: have_prev
+    end function
+    integer(c_int) function sb_diag_stream_end_f32(ctx, sb_last, output4, ws, wd, thc) &
+        bind(C, name="sb_diag_stream_end_f32")
+      import :: c_ptr, c_int, c_float, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(inout) :: sb_last(*)
+      real(c_float), intent(out) :: output4(*), ws(*), wd(*), thc(*)
+    end function
+    integer(c_int) function sb_diag_stream_stats(ctx, steps, seconds) bind(C, name="sb_diag_stream_stats")
+      import :: c_ptr, c_int, c_long, c_double
+      type(c_ptr), value :: ctx
+      integer(c_long), intent(out) :: steps
+      real(c_double), intent(out) :: seconds(3)
     end function
     integer(c_int) function sb_sigmoid_f32(ctx, nx, ny, ary, sm) bind(C, name="sb_sigmoid_f32")
       import :: c_ptr, c_int, c_float
@@ -66,30 +102,39 @@ contains
     integer(c_int) :: rc
     if (.not. c_associated(ctx)) then
       rc = sb_create(ctx, -1_c_int)
-      if (rc /= 0) call sb_fail('sb_create', rc)
+      if (rc /= 0) then
+        call sb_fail('sb_create', rc)
+        ctx = c_null_ptr
+      end if
     end if
   end subroutine sb_ensure
 
-  ! The reference kernels have no error channel on this surface; a failed device call ends
-  ! the interpreter with the library's message rather than returning garbage.
+  ! The reference kernels have no error channel on this surface.  A failed device call leaves its status and the
+  ! library's message here (and on standard error); the routine returns, and the Python layer -- which reads
+  ! last_status() after every call -- raises.  The interpreter is never stopped.
   subroutine sb_fail(what, rc)
     character(len=*), intent(in) :: what
     integer(c_int), intent(in) :: rc
     character(kind=c_char), pointer :: msg(:)
-    character(len=512) :: text
+    character(len=400) :: text
     type(c_ptr) :: cp
     integer :: i
     text = ''
     cp = sb_last_error(ctx)
     if (c_associated(cp)) then
-      call c_f_pointer(cp, msg, [512])
-      do i = 1, 512
+      call c_f_pointer(cp, msg, [400])
+      do i = 1, 400
         if (msg(i) == c_null_char) exit
         text(i:i) = msg(i)
       end do
     end if
-    write (*, '(a,a,a,i0,a,a)') 'seabreeze (f2py surface): ', what, ' failed (', rc, '): ', trim(text)
-    error stop 1
+    last_rc = rc
+    last_msg = 'seabreeze.' // what // ': ' // trim(text)
+    write (0, '(a,a,i0,a)') trim(last_msg), ' (status ', rc, ')'
   end subroutine sb_fail
+
+  subroutine sb_ok()
+    last_rc = 0
+  end subroutine sb_ok
 
 end module sb_f2py_state

@@ -21,14 +21,58 @@ Conventions kept from the reference
 Differences (both are crashes in the reference)
   * ``ci=None`` works: no sea ice, the coast distance is computed once.
   * inputs without a time axis work.
+
+Streaming.  The reference's loop hands the kernel the same ``z``, ``std`` and distance
+field at every step and threads ``ws, wd, thc`` through its return values (ref :222-245).  Where the extension
+offers ``stream_begin / stream_step / stream_end`` (this build does) those planes stay on the device for the whole
+call: a step uploads ``theta`` and the one ``u, v`` plane the pressure vector selects and receives the ``sb_con``
+plane of the step before it, written in place into the result array, so the host copies of step i+1 overlap the
+device work of step i.  Same numbers as the step-by-step path (``SEABREEZE_NO_STREAM=1`` selects that one).
+
+A failed device call (no GPU, out of memory, ...) raises ``RuntimeError`` with the library's message: the
+extension records a status instead of stopping the interpreter, and every call here checks it.
 """
+import os
 import warnings
 
 import numpy as np
 
-from seabreeze import diag as _diag_kernel, get_dist, get_edges
+import seabreeze as _ext
 
-__all__ = ["diag", "c2f", "read_nc"]
+__all__ = ["diag", "c2f", "read_nc", "get_edges", "get_dist", "stream_stats"]
+
+_HAVE_STREAM = all(hasattr(_ext, n) for n in ("stream_begin", "stream_step", "stream_end"))
+
+
+def _check(what):
+    """Raise if the last call into the extension failed (it records a status; it never stops the interpreter)."""
+    if hasattr(_ext, "last_status") and _ext.last_status() != 0:
+        msg = _ext.last_message()
+        msg = msg.decode(errors="replace") if isinstance(msg, bytes) else str(msg)
+        raise RuntimeError(f"{what}: {msg.strip()}")
+
+
+def get_edges(lsm, ci, **kw):
+    out = _ext.get_edges(lsm, ci, **kw)
+    _check("get_edges")
+    return out
+
+
+def get_dist(coast, mask, lon, lat, **kw):
+    out = _ext.get_dist(coast, mask, lon, lat, **kw)
+    _check("get_dist")
+    return out
+
+
+def _diag_kernel(*args, **kw):
+    out = _ext.diag(*args, **kw)
+    _check("diag")
+    return out
+
+
+def stream_stats():
+    """(steps, [host copies, enqueueing, waiting] in seconds) of the last streamed ``diag`` call."""
+    return _ext.stream_stats() if hasattr(_ext, "stream_stats") else (0, [0.0, 0.0, 0.0])
 
 
 def c2f(array):
@@ -101,13 +145,47 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
     nlat, nlon = np.shape(t)[-2:]
     sb_all = np.zeros([nt, nlat, nlon])           # float64 like the reference's (ref :214)
     dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
-    t0 = thc
-    for ts in range(nt):
+
+    def step_inputs(ts):
+        nonlocal dist
         if ci is not None:
             ice = ci[ts] if has_time else ci
             ice = ice.filled(0) if hasattr(ice, "filled") else ice
             dist = _coast_distance(lsm, ice, lon, lat)       # the reference recomputes it every step (:223-228); here: when ice changes
-        tk, vk, uk = (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
+        return (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
+
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    if _HAVE_STREAM and not os.environ.get("SEABREEZE_NO_STREAM"):
+        # z, std, the distance field and the carried state stay on the device; sb_con of step ts-1 arrives while
+        # step ts is being staged, straight into its plane of sb_all (the transpose view of a C-ordered plane is
+        # the Fortran-ordered array the extension writes in place)
+        zf, sdf, pf = c2f(f32(z)), c2f(f32(std)), c2f(f32(pres))
+        scratch = np.zeros((nlon, nlat), order="F")
+        live, out = None, None                       # the distance field the open stream was begun with
+        for ts in range(nt):
+            tk, vk, uk = step_inputs(ts)
+            if live is not dist:
+                if live is not None:                  # the ice moved: close the stream, carry the state over
+                    out, ws, wd, thc = _ext.stream_end(c2f(sb_all[ts - 1]))
+                    _check("stream_end")
+                    ws, wd, thc = c2f(ws), c2f(wd), c2f(thc)
+                _ext.stream_begin(zf, sdf, c2f(f32(dist)), c2f(f32(ws)), c2f(f32(wd)), c2f(f32(thc)))
+                _check("stream_begin")
+                live, fresh = dist, True
+            prev = scratch if (ts == 0 or fresh) else c2f(sb_all[ts - 1])
+            _ext.stream_step(tt, pf, c2f(f32(tk)), c2f(f32(vk)), c2f(f32(uk)), prev, **kwargs)
+            _check("stream_step")
+            fresh = False
+            tt += 1
+        out, ws, wd, thc = _ext.stream_end(c2f(sb_all[nt - 1]))
+        _check("stream_end")
+        out = c2f(out)
+        # what the reference returns as "thc" is the t0 plane (ref :244)
+        return tt, sb_all, np.array(out[1]), np.array(out[2]), np.array(out[3])
+
+    t0 = thc
+    for ts in range(nt):
+        tk, vk, uk = step_inputs(ts)
         out = c2f(_diag_kernel(tt, c2f(pres), c2f(z), c2f(std), c2f(tk), c2f(vk), c2f(uk), c2f(dist),
                                c2f(ws), c2f(wd), c2f(thc), **kwargs))
         sb_all[ts] = out[0]

@@ -22,15 +22,47 @@ import numpy as np
 from . import hip as _hip
 
 
-def split_rows(ny: int, world: int):
-    """Contiguous, near-equal latitude bands: [(r0, r1), ...] with r1 exclusive."""
-    base, rem = divmod(ny, world)
-    out, r = [], 0
-    for k in range(world):
-        n = base + (1 if k < rem else 0)
-        out.append((r, r + n))
-        r += n
-    return out
+def split_rows(ny: int, world: int, cost=None, min_rows: int = 1):
+    """Contiguous latitude bands [(r0, r1), ...] with r1 exclusive.
+
+    cost=None: near-equal row counts.  cost = one non-negative number per row: the rows are cut so that the bands'
+    cost sums are as equal as contiguous cuts allow (SURVEY.md 8(e) "Balance": the coastal band is clustered in
+    latitude, so equal row counts give unequal work).  Every band keeps at least `min_rows` rows (a band must not be
+    thinner than its ghost frame).  Deterministic: every rank computes the same cuts from the same cost vector."""
+    if world < 1 or ny < world * max(1, min_rows):
+        raise ValueError(f"cannot cut {ny} rows into {world} bands of at least {min_rows} rows")
+    if cost is None:
+        base, rem = divmod(ny, world)
+        out, r = [], 0
+        for k in range(world):
+            n = base + (1 if k < rem else 0)
+            out.append((r, r + n))
+            r += n
+        return out
+    c = np.asarray(cost, dtype=np.float64)
+    if c.shape != (ny,) or np.any(c < 0):
+        raise ValueError("cost must hold one non-negative number per row")
+    cum = np.concatenate(([0.0], np.cumsum(c)))
+    total = cum[-1]
+    cuts = [0]
+    for k in range(1, world):
+        # the row boundary whose cumulative cost is nearest k/world of the total, inside the room the minimum
+        # band height leaves on both sides
+        lo, hi = cuts[-1] + min_rows, ny - (world - k) * min_rows
+        target = total * k / world
+        j = int(np.searchsorted(cum, target))
+        if j > 0 and abs(cum[j - 1] - target) <= abs(cum[min(j, ny)] - target):
+            j -= 1
+        cuts.append(min(max(j, lo), hi))
+    cuts.append(ny)
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
+def row_cost(band_mask, nz: int):
+    """Cost of every latitude row in units of the algorithmic bytes of SURVEY.md 8(d): 5 per cell (the four 2-D
+    inputs and sb_con) and nz + 7 per coastal-band cell (its p column, u, v and the state)."""
+    band_mask = np.asarray(band_mask, dtype=bool)
+    return 5.0 * band_mask.shape[1] + (nz + 7.0) * band_mask.sum(axis=1)
 
 
 def fill_ew_ghosts(loc, nx: int, h: int):
@@ -66,7 +98,7 @@ class BandRunner:
     """Owns one rank's device-resident fields and runs seabreeze_diag steps on them."""
 
     def __init__(self, ctx: _hip.Context, torch, dist, rank: int, world: int, nx: int, ny: int, nz: int,
-                 halo: int, dtype=np.float64, comm: str = "torch"):
+                 halo: int, dtype=np.float64, comm: str = "torch", rows=None):
         """comm="torch": ghost rows and moments travel through torch.distributed (`dist`, any backend);
         comm="native": through the library's own RCCL communicator (ctx.comm_init must have run):
         ncclSend/ncclRecv + ncclAllGather enqueued on the compute stream by two C-ABI calls."""
@@ -77,7 +109,7 @@ class BandRunner:
         self.nx, self.ny, self.nz = nx, ny, nz
         self.dtype = np.dtype(dtype)
         self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
-        self.r0, self.r1 = split_rows(ny, world)[rank]
+        self.r0, self.r1 = rows if rows is not None else split_rows(ny, world)[rank]   # rows: this rank's (r0, r1) of a custom cut
         self.nyl = self.r1 - self.r0
         self.h = halo if world > 1 else 0
         self.bnd = _hip.SB_BND_HALO if world > 1 else _hip.SB_BND_GLOBAL

@@ -9,7 +9,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +29,20 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// Streaming form of the f2py-flavour diag (sb_diag_stream_*): what stays on the device between steps, and the
+// pinned staging buffers of the per-step transfers.
+struct DiagStream {
+    bool active = false;
+    int nlons = 0, nlats = 0, esz = 0;
+    DevBuf z, sd, cdist, ws, wd, thc, p1, theta, v, u, out;
+    void *pin_in[2] = {nullptr, nullptr};      // theta | v plane | u plane | p level, two slots
+    void *pin_out[2] = {nullptr, nullptr};     // sb_con plane of a step, two slots
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    long steps = 0;
+    double host_copy_s = 0.0, enqueue_s = 0.0, wait_s = 0.0;   // where the host spent its time (sb_diag_stream_stats)
+};
 
 struct sb_ctx {
     int device = 0;
@@ -65,6 +82,7 @@ struct sb_ctx {
     void *rccl_lib = nullptr;
     void *comm = nullptr;
     int rank = 0, nranks = 1;
+    DiagStream ds;
 };
 
 namespace {
@@ -151,7 +169,9 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.next_flags = flags_next;
     job.next_flags_n = nflag;
     // the lists k_prep compacts: active tiles (k_thc3) and segments that hold band cells (k_wind)
-    if ((rc = ensure(c, c->tile_list, ((size_t)tx * ty + 1) * sizeof(int)))) return rc;
+    // (padded: a k_thc3 workgroup loads its first two candidate entries before it knows how many there are)
+    if ((rc = ensure(c, c->tile_list, ((size_t)tx * ty + (size_t)2 * c->ncu + 2) * sizeof(int)))) return rc;
+    job.tile_pad = 2 * c->ncu;
     const size_t nseg = (size_t)g.nyh * g.nw;
     const size_t seg_cap = (nseg + SB_SEG_PARTS - 1) / SB_SEG_PARTS;
     if ((rc = ensure(c, c->seg_list, seg_cap * SB_SEG_PARTS * sizeof(SbSegEntry)))) return rc;
@@ -218,7 +238,8 @@ int check_dims(sb_ctx *c, int nx, int ny, int nz, int halo, int bnd) {
 template <typename T>
 int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, int bnd, const T *p,
                        const T *u, const T *v, const T *theta, const T *mask, const T *z, const T *sigma, T *ws,
-                       T *wd, T *thc, T *sb_con, const sb_tunables *tun, void *stream, int phases = 3) {
+                       T *wd, T *thc, T *sb_con, const sb_tunables *tun, void *stream, int phases = 3,
+                       int mask_halo = -1, int level_rule = 0) {
     int rc = check_dims<T>(c, nx, ny, nz, halo, bnd);
     if (rc) return rc;
     if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
@@ -238,6 +259,12 @@ int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, 
     job.thr_ch = (T)d.thresh_windch; job.thr_thc = (T)d.thresh_thc; job.maxdist = (T)d.maxdist_km;
     job.fill = T(0);                                              // ref :176
     job.p = p; job.u = u; job.v = v; job.theta = theta; job.mask = mask; job.z = z; job.sigma = sigma;
+    // mask may sit in a wider ghost frame than theta, z and sigma (UM layout: tdims_l against tdims_s)
+    const int hl = mask_halo < 0 ? halo : mask_halo;
+    if (hl < halo) return fail(c, SB_ERR_ARG, "the ghost frame of mask must be at least as wide as that of theta, z, sigma");
+    job.mask_ld = nx + 2 * hl;
+    job.mask_off = (unsigned)((hl - halo) * job.mask_ld + (hl - halo));
+    job.level_rule = level_rule;
     job.ws = ws; job.wd = wd; job.thc = thc; job.sb_con = sb_con; job.out = nullptr;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     return run_diag<T>(c, job, st, phases);
@@ -329,6 +356,7 @@ int diag_dev(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T *
     job.thr_thc = thresh_thc; job.maxdist = maxdist;
     job.fill = T(2.0E20);                                         // ref :173
     job.p = p; job.u = u; job.v = v; job.theta = theta; job.mask = cdist; job.z = z; job.sigma = std_;
+    job.mask_ld = nlons; job.mask_off = 0; job.level_rule = 0;
     job.ws = ws; job.wd = wd; job.thc = thc; job.sb_con = nullptr; job.out = output;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (job.g.rows < 1) return SB_OK;                             // nlats == 1: the reference loop is empty
@@ -392,6 +420,55 @@ int seabreeze_diag_host(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz,
     return s.finish();
 }
 
+// UM vn10.7 field layout (ref: UM/vn10.7/sea_breeze_diag.F90:55-117): p, u, v, sb_con on pdims and windspeed,
+// winddir, thc on tdims (no ghost cells); theta, z, sigma on tdims_s (ghost width hs); mask on tdims_l (hl >= hs).
+template <typename T>
+int seabreeze_diag_um_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int hs, int hl, const T *p,
+                          const T *u, const T *v, T *theta, const T *z, const T *sigma, const T *mask, T *ws, T *wd,
+                          T *thc, T *sb_con, int flags, int *error, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!error) return fail(c, SB_ERR_ARG, "null error pointer");
+    *error = 0;
+    if (ny < 1 || nz < 1 || nx < 1) { *error = 1; return SB_OK; }           // ref: UM :198-202
+    if (hs < 0 || hl < hs) return fail(c, SB_ERR_ARG, "UM layout: need 0 <= halo_s <= halo_l");
+    if (flags & ~(SB_UM_THETA_TO_T0 | SB_UM_LEVEL_WALK)) return fail(c, SB_ERR_ARG, "unknown UM flag");
+    const int bnd = hs > 0 ? SB_BND_HALO : SB_BND_GLOBAL;
+    int rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, hs, bnd, p, u, v, theta, mask, z, sigma, ws, wd, thc,
+                                   sb_con, nullptr, stream, 3, hl, (flags & SB_UM_LEVEL_WALK) ? 1 : 0);
+    if (rc) return rc;
+    if (flags & SB_UM_THETA_TO_T0) {
+        hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+        HIPCHK(c, sb_launch_theta_to_t0<T>(theta, z, sigma, (size_t)(nx + 2 * hs) * (ny + 2 * hs), (const T *)c->stats, st));
+    }
+    return SB_OK;
+}
+
+template <typename T>
+int seabreeze_diag_um_host(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int hs, int hl, const T *p,
+                           const T *u, const T *v, T *theta, const T *z, const T *sigma, const T *mask, T *ws, T *wd,
+                           T *thc, T *sb_con, int flags, int *error) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!error) return fail(c, SB_ERR_ARG, "null error pointer");
+    *error = 0;
+    if (ny < 1 || nz < 1 || nx < 1) { *error = 1; return SB_OK; }
+    if (hs < 0 || hl < hs) return fail(c, SB_ERR_ARG, "UM layout: need 0 <= halo_s <= halo_l");
+    if (!p || !u || !v || !theta || !mask || !z || !sigma || !ws || !wd || !thc || !sb_con)
+        return fail(c, SB_ERR_ARG, "null array pointer");
+    const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, ns = (size_t)(nx + 2 * hs) * (ny + 2 * hs),
+                 nl = (size_t)(nx + 2 * hl) * (ny + 2 * hl);
+    Stager s(c);
+    T *dp = s.in(p, n3), *du = s.in(u, n3), *dv = s.in(v, n3);
+    T *dth = s.in(theta, ns), *dz = s.in(z, ns), *dsg = s.in(sigma, ns), *dm = s.in(mask, nl);
+    T *dws = s.in(ws, n2), *dwd = s.in(wd, n2), *dthc = s.in(thc, n2), *dsb = s.in(sb_con, n2);
+    if (s.rc) return s.rc;
+    int rc = seabreeze_diag_um_dev<T>(c, timestep_s, tn, nx, ny, nz, hs, hl, dp, du, dv, dth, dz, dsg, dm, dws, dwd, dthc,
+                                      dsb, flags, error, nullptr);
+    if (rc) return rc;
+    s.back(ws, dws, n2); s.back(wd, dwd, n2); s.back(thc, dthc, n2); s.back(sb_con, dsb, n2);
+    if (flags & SB_UM_THETA_TO_T0) s.back(theta, dth, ns);
+    return s.finish();
+}
+
 template <typename T>
 int diag_host(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T *theta, const T *v, const T *u,
               const T *cdist, T *ws, T *wd, T *thc, T target_plev, T thresh_wind, T thresh_winddir, T thresh_windch,
@@ -434,6 +511,161 @@ int diag_host(sb_ctx *c, int tn, const T *p, const T *z, const T *std_, const T 
     const size_t nwritten = (size_t)nlons * (nlats > 0 ? nlats - 1 : 0);
     for (int pl = 0; pl < 4 && nwritten > 0; ++pl) s.back(output + (size_t)pl * n2, dout + (size_t)pl * n2, nwritten);
     return s.finish();
+}
+
+// ---- streaming diag (f2py flavour): SURVEY.md 8(f) rank 1 ---------------------------------------------------
+// The reference's Python driver calls diag once per timestep with the same z, std, cdist and threads windspeed,
+// winddir, thc through its return values (ref: python_wrapper/seabreezediag/__init__.py:222-245).  Here those six
+// planes stay on the device between sb_diag_stream_begin and sb_diag_stream_end; a step uploads theta and the one
+// u, v plane its 1-D p selects through pinned, double-buffered staging (asynchronous copies), and brings back only
+// the sb_con plane -- of the PREVIOUS step, so that the host copies of step i+1 overlap the device work of step i.
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void stream_release(sb_ctx *c) {
+    DiagStream &d = c->ds;
+    for (DevBuf *b : {&d.z, &d.sd, &d.cdist, &d.ws, &d.wd, &d.thc, &d.p1, &d.theta, &d.v, &d.u, &d.out})
+        if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (int k = 0; k < 2; ++k) {
+        if (d.pin_in[k]) (void)hipHostFree(d.pin_in[k]);
+        if (d.pin_out[k]) (void)hipHostFree(d.pin_out[k]);
+        if (d.ev_in[k]) (void)hipEventDestroy(d.ev_in[k]);
+        if (d.ev_out[k]) (void)hipEventDestroy(d.ev_out[k]);
+        d.pin_in[k] = d.pin_out[k] = nullptr;
+        d.ev_in[k] = d.ev_out[k] = nullptr;
+    }
+    d.pin_in_cap = d.pin_out_cap = 0;
+    d.active = false;
+}
+
+template <typename T>
+int stream_begin(sb_ctx *c, int nlons, int nlats, const T *z, const T *sd, const T *cdist, const T *ws, const T *wd,
+                 const T *thc) {
+    int rc = check_dims<T>(c, nlons, nlats, 1, 0, SB_BND_WRAPPER);
+    if (rc) return rc;
+    if (!z || !sd || !cdist || !ws || !wd || !thc) return fail(c, SB_ERR_ARG, "null array pointer");
+    DiagStream &d = c->ds;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n2 = (size_t)nlons * nlats, b2 = n2 * sizeof(T);
+    for (DevBuf *b : {&d.z, &d.sd, &d.cdist, &d.ws, &d.wd, &d.thc, &d.theta, &d.v, &d.u})
+        if ((rc = ensure(c, *b, b2))) return rc;
+    if ((rc = ensure(c, d.out, 4 * b2))) return rc;
+    if ((rc = ensure(c, d.p1, 16))) return rc;
+    const size_t in_bytes = 3 * b2 + 16, out_bytes = b2;
+    if (d.pin_in_cap < in_bytes || d.pin_out_cap < out_bytes) {
+        for (int k = 0; k < 2; ++k) {
+            if (d.pin_in[k]) (void)hipHostFree(d.pin_in[k]);
+            if (d.pin_out[k]) (void)hipHostFree(d.pin_out[k]);
+            d.pin_in[k] = d.pin_out[k] = nullptr;
+            HIPCHK(c, hipHostMalloc(&d.pin_in[k], in_bytes, hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc(&d.pin_out[k], out_bytes, hipHostMallocDefault));
+        }
+        d.pin_in_cap = in_bytes;
+        d.pin_out_cap = out_bytes;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!d.ev_in[k]) HIPCHK(c, hipEventCreateWithFlags(&d.ev_in[k], hipEventDisableTiming));
+        if (!d.ev_out[k]) HIPCHK(c, hipEventCreateWithFlags(&d.ev_out[k], hipEventDisableTiming));
+    }
+    const T *src[6] = {z, sd, cdist, ws, wd, thc};
+    DevBuf *dst[6] = {&d.z, &d.sd, &d.cdist, &d.ws, &d.wd, &d.thc};
+    for (int i = 0; i < 6; ++i) HIPCHK(c, hipMemcpyAsync(dst[i]->p, src[i], b2, hipMemcpyHostToDevice, c->stream));
+    // the output planes start from zero: row nlats of every plane is never written by the kernels (ref :165)
+    HIPCHK(c, hipMemsetAsync(d.out.p, 0, 4 * b2, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    d.nlons = nlons; d.nlats = nlats; d.esz = (int)sizeof(T);
+    d.steps = 0;
+    d.host_copy_s = d.enqueue_s = d.wait_s = 0.0;
+    d.active = true;
+    return SB_OK;
+}
+
+// sb_con of the step in `slot` -> rows 1..nlats-1 of a caller's double plane (what the reference's driver keeps)
+template <typename T>
+void stream_copy_out(const DiagStream &d, int slot, double *dst) {
+    const T *src = (const T *)d.pin_out[slot];
+    const size_t n = (size_t)d.nlons * (d.nlats > 0 ? d.nlats - 1 : 0);
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+
+template <typename T>
+int stream_step(sb_ctx *c, int tn, const T *p, int nps, const T *theta, const T *v, const T *u, T target_plev,
+                T thresh_wind, T thresh_winddir, T thresh_windch, T thresh_thc, T target_time, T maxdist, T timestep,
+                double *sb_con_prev, int *have_prev) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    DiagStream &d = c->ds;
+    if (!d.active || d.esz != (int)sizeof(T)) return fail(c, SB_ERR_ARG, "sb_diag_stream_step without a matching sb_diag_stream_begin");
+    if (!p || nps < 1 || !theta || !v || !u || !have_prev) return fail(c, SB_ERR_ARG, "bad stream_step arguments");
+    const size_t n2 = (size_t)d.nlons * d.nlats, b2 = n2 * sizeof(T);
+    int lev = 0;                                                 // as diag_host: the level is known on the host
+    {
+        const T tp = target_plev * T(100.);
+        T best = std::fabs(p[0] - tp);
+        for (int k = 1; k < nps; ++k) {
+            const T a = std::fabs(p[k] - tp);
+            if (a < best) { best = a; lev = k; }
+        }
+    }
+    const int slot = (int)(d.steps & 1);
+    double t0 = now_s();
+    // the staging slot was last read by the upload of two steps ago
+    if (d.steps >= 2) HIPCHK(c, hipEventSynchronize(d.ev_in[slot]));
+    double t1 = now_s();
+    d.wait_s += t1 - t0;
+    char *pin = (char *)d.pin_in[slot];
+    {
+        // three planes, three host threads: a single memcpy stream would be the longest item of the step
+        auto f1 = std::async(std::launch::async, [&] { std::memcpy(pin + b2, v + (size_t)lev * n2, b2); });
+        auto f2 = std::async(std::launch::async, [&] { std::memcpy(pin + 2 * b2, u + (size_t)lev * n2, b2); });
+        std::memcpy(pin, theta, b2);
+        std::memcpy(pin + 3 * b2, p + lev, sizeof(T));
+        f1.get();
+        f2.get();
+    }
+    double t2 = now_s();
+    d.host_copy_s += t2 - t1;
+    HIPCHK(c, hipMemcpyAsync(d.theta.p, pin, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.v.p, pin + b2, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.u.p, pin + 2 * b2, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.p1.p, pin + 3 * b2, sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(d.ev_in[slot], c->stream));
+    int rc = diag_dev<T>(c, tn, (const T *)d.p1.p, (const T *)d.z.p, (const T *)d.sd.p, (const T *)d.theta.p,
+                         (const T *)d.v.p, (const T *)d.u.p, (const T *)d.cdist.p, (T *)d.ws.p, (T *)d.wd.p, (T *)d.thc.p,
+                         target_plev, thresh_wind, thresh_winddir, thresh_windch, thresh_thc, target_time, maxdist,
+                         timestep, 1, d.nlons, d.nlats, (T *)d.out.p, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(d.pin_out[slot], d.out.p, b2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(d.ev_out[slot], c->stream));
+    double t3 = now_s();
+    d.enqueue_s += t3 - t2;
+    // the previous step's sb_con: its copy finished while this step's planes were being staged
+    *have_prev = 0;
+    if (d.steps > 0 && sb_con_prev) {
+        HIPCHK(c, hipEventSynchronize(d.ev_out[1 - slot]));
+        double t4 = now_s();
+        d.wait_s += t4 - t3;
+        stream_copy_out<T>(d, 1 - slot, sb_con_prev);
+        d.host_copy_s += now_s() - t4;
+        *have_prev = 1;
+    }
+    d.steps++;
+    return SB_OK;
+}
+
+template <typename T>
+int stream_end(sb_ctx *c, double *sb_con_last, T *output4, T *ws, T *wd, T *thc) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    DiagStream &d = c->ds;
+    if (!d.active || d.esz != (int)sizeof(T)) return fail(c, SB_ERR_ARG, "sb_diag_stream_end without a matching sb_diag_stream_begin");
+    const size_t n2 = (size_t)d.nlons * d.nlats, b2 = n2 * sizeof(T);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (d.steps > 0 && sb_con_last) stream_copy_out<T>(d, (int)((d.steps - 1) & 1), sb_con_last);
+    if (output4) HIPCHK(c, hipMemcpyAsync(output4, d.out.p, 4 * b2, hipMemcpyDeviceToHost, c->stream));
+    if (ws) HIPCHK(c, hipMemcpyAsync(ws, d.ws.p, b2, hipMemcpyDeviceToHost, c->stream));
+    if (wd) HIPCHK(c, hipMemcpyAsync(wd, d.wd.p, b2, hipMemcpyDeviceToHost, c->stream));
+    if (thc) HIPCHK(c, hipMemcpyAsync(thc, d.thc.p, b2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    d.active = false;
+    return SB_OK;
 }
 
 template <typename T>
@@ -638,6 +870,7 @@ int sb_destroy(sb_ctx *c) {
     if (!c) return SB_OK;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)sb_comm_finalize(c);
+    stream_release(c);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -716,6 +949,14 @@ int sb_profile_end(sb_ctx *c, double avg_ms[SB_PROF_KERNELS], int *ncalls) {
     c->prof_ev.clear();
     c->prof_mask.clear();
     c->prof_calls = c->prof_max = 0;
+    return SB_OK;
+}
+
+int sb_diag_stream_stats(sb_ctx *c, long *steps, double seconds[3]) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!steps || !seconds) return fail(c, SB_ERR_ARG, "null pointer");
+    *steps = c->ds.steps;
+    seconds[0] = c->ds.host_copy_s; seconds[1] = c->ds.enqueue_s; seconds[2] = c->ds.wait_s;
     return SB_OK;
 }
 
@@ -821,6 +1062,31 @@ int sb_last_counters(sb_ctx *c, long long counters[4]) {
     }                                                                                                              \
     int sb_dist_window_##SFX(int nx, int ny, const T *lon, const T *lat, T maxdist, int *k) {                       \
         return dist_window<T>(nx, ny, lon, lat, maxdist, k);                                                        \
+    }                                                                                                              \
+    int sb_diag_stream_begin_##SFX(sb_ctx *c, int nlons, int nlats, const T *z, const T *sd, const T *cdist,         \
+                                   const T *ws, const T *wd, const T *thc) {                                        \
+        return stream_begin<T>(c, nlons, nlats, z, sd, cdist, ws, wd, thc);                                         \
+    }                                                                                                              \
+    int sb_diag_stream_step_##SFX(sb_ctx *c, int tn, const T *p, int nps, const T *theta, const T *v, const T *u,   \
+                                  T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, double *sb_con_prev,              \
+                                  int *have_prev) {                                                                 \
+        return stream_step<T>(c, tn, p, nps, theta, v, u, a0, a1, a2, a3, a4, a5, a6, a7, sb_con_prev, have_prev);  \
+    }                                                                                                              \
+    int sb_diag_stream_end_##SFX(sb_ctx *c, double *sb_con_last, T *output4, T *ws, T *wd, T *thc) {                \
+        return stream_end<T>(c, sb_con_last, output4, ws, wd, thc);                                                 \
+    }                                                                                                              \
+    int sb_seabreeze_diag_um_##SFX(sb_ctx *c, T dt, int tn, int nx, int ny, int nz, int hs, int hl, const T *p,     \
+                                   const T *u, const T *v, T *theta, const T *z, const T *sigma, const T *mask,     \
+                                   T *ws, T *wd, T *thc, T *sb_con, int flags, int *error) {                        \
+        return seabreeze_diag_um_host<T>(c, dt, tn, nx, ny, nz, hs, hl, p, u, v, theta, z, sigma, mask, ws, wd, thc, \
+                                         sb_con, flags, error);                                                     \
+    }                                                                                                              \
+    int sb_seabreeze_diag_um_##SFX##_dev(sb_ctx *c, T dt, int tn, int nx, int ny, int nz, int hs, int hl,           \
+                                         const T *p, const T *u, const T *v, T *theta, const T *z, const T *sigma,  \
+                                         const T *mask, T *ws, T *wd, T *thc, T *sb_con, int flags, int *error,     \
+                                         void *stream) {                                                            \
+        return seabreeze_diag_um_dev<T>(c, dt, tn, nx, ny, nz, hs, hl, p, u, v, theta, z, sigma, mask, ws, wd, thc, \
+                                        sb_con, flags, error, stream);                                              \
     }
 
 SB_DEFINE(double, f64)

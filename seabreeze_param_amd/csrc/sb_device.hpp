@@ -198,7 +198,8 @@ struct DiagJob {
     int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius
     int *ticket;                    // spare device word (zeroed by k_scan)
     // lists k_prep compacts between k_scan and the kernels that consume them
-    int *tile_list;                 // [0] = number of active tiles, [1..] their indices in row-major order
+    int *tile_list;                 // [0] = number of active tiles, [1..] their indices in row-major order, then
+    int tile_pad;                   //   tile_pad entries of -1 (two per k_thc3 workgroup)
     SbSegEntry *seg_list;           // SB_SEG_PARTS sub-lists of seg_cap entries: the segments that hold band cells
     int *seg_count;                 // entries in each sub-list
     int seg_cap;

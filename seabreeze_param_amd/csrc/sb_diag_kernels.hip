@@ -284,6 +284,26 @@ __global__ __launch_bounds__(256) void k_t0(DiagJob<T> job) {
         job.out[(size_t)g.nx * g.ny + (size_t)yi * g.nx + xi] = t0v;
 }
 
+// theta <- t0 in place over the whole ghost-celled frame: what the UM copy does before its point loop
+// (ref: UM/vn10.7/sea_breeze_diag.F90:210-211); optional, after the diagnostic has read theta.
+template <typename T>
+__global__ __launch_bounds__(256) void k_theta_to_t0(T *__restrict__ theta, const T *__restrict__ z,
+                                                     const T *__restrict__ sigma, size_t n, const T *__restrict__ stats) {
+    const T sd = stats[0], r = stats[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        theta[i] = sb_t0<T>(theta[i], z[i], sigma[i], sd, r);
+}
+
+template <typename T>
+hipError_t sb_launch_theta_to_t0(T *theta, const T *z, const T *sigma, size_t n, const T *stats, hipStream_t st) {
+    int nblk = (int)((n + 255) / 256);
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(k_theta_to_t0<T>, dim3(nblk), dim3(256), 0, st, theta, z, sigma, n, stats);
+    return hipGetLastError();
+}
+template hipError_t sb_launch_theta_to_t0<float>(float *, const float *, const float *, size_t, const float *, hipStream_t);
+template hipError_t sb_launch_theta_to_t0<double>(double *, const double *, const double *, size_t, const double *, hipStream_t);
+
 // ------------------------------------------------------------------------------------
 // k_prep: the small jobs between k_scan and the kernels that consume its flags, one role per
 // workgroup (18 workgroups, ~2 us), so that neither the 256 persistent workgroups of k_thc3 nor
@@ -291,7 +311,8 @@ __global__ __launch_bounds__(256) void k_t0(DiagJob<T> job) {
 //   block 0               k_scan's per-workgroup moments merged, in the fixed order and tree of
 //                         k_moments_final, into the sigmoid scalars (or published as this band's
 //                         moments for the multi-GPU gather)
-//   block 1               tile flags -> row-major list of active tiles: tile_list[0] = count
+//   block 1               tile flags -> row-major list of active tiles: tile_list[0] = count, then the tiles, then
+//                         tile_pad entries of -1
 //   blocks 2 .. 2+PARTS-1 band plane -> the 64-cell segments that hold band cells, each part a
 //                         contiguous range of segments with its own sub-list (ascending order)
 // ------------------------------------------------------------------------------------
@@ -338,6 +359,9 @@ __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments 
         for (int t = t0; t < t1; ++t)
             if (job.tile_nnmax[t] != 0) job.tile_list[1 + at++] = t;
         if (tid == 0) job.tile_list[0] = total;
+        // the list ends in -1 entries, two per k_thc3 workgroup: a workgroup reads its first two positions before
+        // it knows the count, and finds its end without it
+        for (int i = tid; i < job.tile_pad; i += PREP_NT) job.tile_list[1 + total + i] = -1;
         return;
     }
     const int part = (int)blockIdx.x - 2;

@@ -47,6 +47,10 @@ void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStream_t st);   // nt: 512 or 1024 threads
 
+// theta <- theta - (gmma*z)*sigmoid(sigma) over n cells, with the scalars the last diag call left in `stats`
+template <typename T>
+hipError_t sb_launch_theta_to_t0(T *theta, const T *z, const T *sigma, size_t n, const T *stats, hipStream_t st);
+
 template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st);
 // phi: d2r*lat (ny), lamf: folded d2r*lon (nx), both device pointers

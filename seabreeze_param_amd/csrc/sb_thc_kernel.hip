@@ -19,6 +19,15 @@
 // k_thc3 tiles are 32 longitudes wide: with the halo a staged row is exactly one 64-lane chunk (H = 16), so
 // no lane of a staging load, an exp or an LDS write is padding.  48 latitudes by default: on the N1280 grid
 // the coastal band touches 670 such tiles (575 of 64 rows, 1004 of 32) and tiles x staged rows is smallest there.
+#ifndef THC_SKIP
+#define THC_SKIP 0                // diagnostic builds only: bit 0 no sigmoid, 1 no scans, 2 no radius probes, 3 no sums, 4 no prefetch loads
+#endif
+#ifndef THC_PC16
+#define THC_PC16 1                 // count table rows 16 banks apart (0: the pitch of the fp64 tables)
+#endif
+#ifndef THC_QI
+#define THC_QI 0                  // list entries a thread takes through the search rounds together; 0: by workgroup size
+#endif
 #define THC_TX 32
 #define THC_TY 48
 #define THC_TYL 64                // taller tiles, by sb_set_tile_rows only
@@ -105,6 +114,30 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- buffer loads: a 128-bit resource descriptor per field (wave-uniform base + size), a 32-bit byte offset per
+// lane and a scalar byte offset per row.  One instruction per load, no 64-bit address arithmetic: the staging of a
+// tile is issue-bound, and a row's offset is the same for all 64 lanes of the wave that owns it.
+typedef unsigned int sb_u2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T sb_buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ double sb_buf_ld<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const sb_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+template <>
+__device__ __forceinline__ float sb_buf_ld<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sb_make_rsrc(const void *p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0xfffffff0ull ? 0xfffffff0ull : bytes), 0x00020000);
+}
+
+template <bool FLY>
+struct ThcBufs {
+    __amdgpu_buffer_rsrc_t th, zz, sg, cls;       // theta (FLY) or t0; z; sigma; land-side plane
+};
+
 // everything a thread holds of a tile between the issue of its loads and A1
 template <typename T, int NC, int NCH, bool FLY>
 struct ThcRegs {
@@ -112,24 +145,27 @@ struct ThcRegs {
     T zz[FLY ? NC : 1], sg[FLY ? NC : 1];
     uint32_t lw[NC];               // the 32-bit half of the land-side word that holds the cell
     int xcol[NCH];                 // array column of each chunk, -1: no such cell
-    unsigned okm;                  // bit k: cell k exists
+    unsigned rowok;                // bit ri: row ri of the wave exists (wave-uniform)
     uint64_t bw0, bw1;             // the two words that hold the band bits of tile row tid (tid < TY)
     int bsh;                       // their shift, -1: no such row
     T c0;                          // the tile's offset
 };
 
 template <typename T, int TX, int TY, int H, int NT, bool FLY, int RPW, int NCH>
-__device__ __forceinline__ void thc_issue(const DiagJob<T> &job, int tile, ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+__device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<FLY> &B, int tile, int wvu,
+                                          ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
     constexpr int W = TX + 2 * H;
     const Geo g = job.g;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int ntx = job.thc_ntx;
-    const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
+    const int ty = tile / ntx;                   // tile is wave-uniform (scalar division)
+    const int x0 = (tile - ty * ntx) * TX, y0 = ty * TY;
     int X, Y;
     sb_map_cell(g, x0, y0, X, Y);
     const unsigned unxh = (unsigned)g.nxh;
     const unsigned i00 = (unsigned)Y * unxh + (unsigned)X;
     const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
+    unsigned colb[NCH], clsb[NCH];               // byte offsets of the lane's column: in a field row, in a row of the bit plane
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = ch * SB_WAVE + lane;
@@ -148,36 +184,31 @@ __device__ __forceinline__ void thc_issue(const DiagJob<T> &job, int tile, ThcRe
             sb_map_cell(g, xs, y0, Xc, Yd);
         }
         R.xcol[ch] = ok ? Xc : -1;
+        const unsigned xc = ok ? (unsigned)Xc : 0u;              // every load is unconditional, from a clamped address
+        colb[ch] = xc * (unsigned)sizeof(T);
+        clsb[ch] = (xc >> 5) * 4u;
     }
-    R.okm = 0;
-    const uint32_t *cls32 = (const uint32_t *)job.clsbits;
-    // Every load of the tile is unconditional, from a clamped address: a load under a branch is
-    // waited for inside the branch, one round trip after the other.
+    R.rowok = 0;
 #pragma unroll
     for (int ri = 0; ri < RPW; ++ri) {
-        const int r = wv * RPW + ri;
-        const int ys = y0 - H + r;
+        const int ys = y0 - H + wvu * RPW + ri;  // scalar: the wave's row
         int Yr;
         bool rowok = true;
         if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-        const unsigned rowbase = (unsigned)Yr * unxh, wordbase = (unsigned)Yr * (unsigned)g.nw;
+        const unsigned rowb = (unsigned)Yr * unxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
+        R.rowok |= (rowok ? 1u : 0u) << ri;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int k = ri * NCH + ch;
-            const bool ok = rowok && R.xcol[ch] >= 0;
-            const unsigned xc = ok ? (unsigned)R.xcol[ch] : 0u;
-            const unsigned ii = ok ? rowbase + xc : i00;                       // i00: any cell that exists
-            if constexpr (FLY) { R.th[k] = job.theta[ii]; R.zz[k] = job.z[ii]; R.sg[k] = job.sigma[ii]; }
-            else R.th[k] = job.t0[ii];
-            R.lw[k] = cls32[(size_t)(wordbase + (xc >> 6)) * 2 + ((xc >> 5) & 1u)];
-            R.okm |= (ok ? 1u : 0u) << k;
+            R.th[k] = sb_buf_ld<T>(B.th, colb[ch], rowb);
+            if constexpr (FLY) { R.zz[k] = sb_buf_ld<T>(B.zz, colb[ch], rowb); R.sg[k] = sb_buf_ld<T>(B.sg, colb[ch], rowb); }
+            R.lw[k] = __builtin_amdgcn_raw_buffer_load_b32(B.cls, clsb[ch], wordb, 0);
         }
     }
     // the tile's offset -- any common value conditions the sums, and theta at the tile origin needs
     // no sigmoid -- and the band words
-    if constexpr (FLY) R.c0 = job.theta[i00];
-    else R.c0 = job.t0[i00];
+    R.c0 = sb_buf_ld<T>(B.th, 0u, i00 * (unsigned)sizeof(T));
     {
         const bool have = tid < TY && y0 + tid < g.rows;
         const int Xb = x0 + g.h, wi = Xb >> 6;
@@ -188,10 +219,34 @@ __device__ __forceinline__ void thc_issue(const DiagJob<T> &job, int tile, ThcRe
     }
 }
 
+// reciprocal of a small positive integer held in a double: v_rcp_f64 and two Newton steps (within an ulp of 1/n)
+__device__ __forceinline__ double sb_inv(double n) {
+    double q = __builtin_amdgcn_rcp(n);
+    q = __builtin_fma(q, __builtin_fma(-n, q, 1.0), q);
+    q = __builtin_fma(q, __builtin_fma(-n, q, 1.0), q);
+    return q;
+}
+
+// largest value of a wave, valid in lane 63 (DPP, no LDS crossbar)
+__device__ __forceinline__ int sb_wave_max_to_last(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;                                    // values are >= 0, lanes without a source contribute 0
+}
+
 template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF>     // WF: k_wind applies the update (job.wind_final)
 __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     constexpr int NWV = NT / SB_WAVE;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
+    // The count table has a pitch of its own: its 2-byte entries make consecutive rows of pitch W + 1 (65 entries =
+    // 32.5 banks) land on the same LDS banks, and a half-wave of the search holds band cells of two or three
+    // rows.  A pitch of 16 banks modulo 32 (where the LDS holds it) moves the rows apart: THC_PC16 below.
+    constexpr int PC = THC_PC16 && (size_t)(HT + 1) * (((W + 1 + 31) / 64) * 64 + 32) * 2 + 2 * (size_t)(HT + 1) * P * 8 < 150000
+                           ? ((W + 1 + 31) / 64) * 64 + 32 : P;
     constexpr int RPW = HT / NWV;                // consecutive table rows a wave owns
     constexpr int NCH = (W + SB_WAVE - 1) / SB_WAVE;
     constexpr int NC = RPW * NCH;
@@ -201,13 +256,13 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     static_assert(H % 4 == 0 && TX <= SB_WAVE && TY <= SB_WAVE && TY <= NT && NC <= 32, "tile shape");
     static_assert((size_t)W * HT < 65536, "u16 count table");
     // The next tile's inputs are prefetched into registers a whole tile ahead -- except where a thread holds two
-    // chunks of every row in double precision (halos of 24 and 32 cells): there the prefetch registers would
-    // spill, and the loads are issued when the tile's turn comes.
+    // chunks of every row (halos of 24 and 32 cells): there the prefetch registers would spill, and the loads are
+    // issued when the tile's turn comes.
     constexpr bool PF = NCH == 1;
     __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
     __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
-    __shared__ unsigned short sC[(HT + 1) * P];  // SAT of land-side count
-    __shared__ double pA[NWV * W], pL[NWV * W];  // per-wave band totals of every column, prefixed along longitude
+    __shared__ unsigned short sC[(HT + 1) * PC]; // SAT of land-side count (its own pitch, see PC)
+    __shared__ double pA[NWV * W], pL[NWV * W];  // per-wave band totals of every column
     __shared__ int pC[NWV * W];
     __shared__ uint64_t s_land[2][HT * NCH];     // land-side bits of every staged row; two buffers: the search of tile i reads
                                                  // them while a wave that is ahead already stages tile i + 1
@@ -215,7 +270,8 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     __shared__ unsigned short s_cell[TX * TY];   // the tile's band cells, compacted
 
     const Geo g = job.g;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: row offsets stay scalar
     const int ntx = job.thc_ntx;
     const uint64_t le_mask = ~0ull >> (63 - lane);               // lanes 0 .. lane
 
@@ -224,27 +280,36 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     const long long w_begin = wall_clock64();
     for (int i = 0; i < SB_NSTAMP; ++i) acc[i] = 0;
 #endif
-    // ---- prologue: the list of active tiles and the sigmoid scalars are k_prep's work -------------
-    const int nactive = job.tile_list[0];
+    // ---- prologue: the list of active tiles and the sigmoid scalars are k_prep's work.  The kernel starts from
+    // cold caches, so what counts is the number of dependent round trips: kernel arguments -> {this workgroup's
+    // first two list entries, the sigmoid scalars} -> the first tile's inputs.  The list ends in -1 entries, so the
+    // count of active tiles is not needed.
     const int G = (int)gridDim.x;
     int pos = (int)blockIdx.x;
-    int tile = pos < nactive ? job.tile_list[1 + pos] : -1;
-    ThcRegs<T, NC, NCH, FLY> R;
-    if (PF && tile >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, tile, R);
-    // the position after this one: its list entry is loaded a whole tile before it is needed
-    int next_tile = pos + G < nactive ? job.tile_list[1 + pos + G] : -1;
+    const int cand0 = job.tile_list[1 + pos], cand1 = job.tile_list[1 + pos + G];
     T sd = T(0), rr = T(0);
     if constexpr (FLY) { sd = job.stats[0]; rr = job.stats[1]; }
-    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * P] = 0; }
+    const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
+    ThcBufs<FLY> B;
+    B.th = sb_make_rsrc(FLY ? (const void *)job.theta : (const void *)job.t0, fbytes);
+    B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.t0, fbytes);
+    B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.t0, fbytes);
+    B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
+    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * PC] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+    int tile = __builtin_amdgcn_readfirstlane(cand0);
+    int next_tile = __builtin_amdgcn_readfirstlane(cand1);
+    ThcRegs<T, NC, NCH, FLY> R;
+    if (PF && tile >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, wv, R);
     __syncthreads();
     SB_T(0);                                   // prologue
 
     int par = 0;
     while (tile >= 0) {
-        const int x0 = (tile % ntx) * TX, y0 = (tile / ntx) * TY;
-        if (!PF) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, tile, R);
-        // ---- A1: registers -> t0 - c0, band totals -------------------------------------------------
+        const int tyi = tile / ntx;
+        const int x0 = (tile - tyi * ntx) * TX, y0 = tyi * TY;
+        if (!PF) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, wv, R);
+        // ---- A1: registers -> t0 - c0, column sums of the wave's band of rows -------------------------
         if (tid < TY) {
             uint64_t w = 0;
             if (R.bsh >= 0) {
@@ -271,16 +336,17 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
 #pragma unroll
             for (int ri = 0; ri < RPW; ++ri) {
                 const int r = wv * RPW + ri;
+                const bool rowok = (R.rowok >> ri) & 1u;         // wave-uniform
                 unsigned carryC = 0;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
                     const int k = ri * NCH + ch;
-                    const bool ok = (R.okm >> k) & 1u;
+                    const bool ok = rowok && R.xcol[ch] >= 0;
                     const unsigned land = ok ? ((R.lw[k] >> (R.xcol[ch] & 31)) & 1u) : 0u;
                     T t0v = R.th[k];
                     if constexpr (FLY) {
                         // the sigmoid only where a lane of the wave stands on land (wave-uniform branch)   ref :166-167
-                        if (__ballot(ok && R.zz[k] != T(0)) != 0) t0v = sb_t0<T>(R.th[k], R.zz[k], R.sg[k], sd, rr);
+                        if (!(THC_SKIP & 1) && __ballot(ok && R.zz[k] != T(0)) != 0) t0v = sb_t0<T>(R.th[k], R.zz[k], R.sg[k], sd, rr);
                     }
                     d[k] = ok ? (double)t0v - c0 : 0.0;
                     const uint64_t lm = __ballot(land);
@@ -292,31 +358,28 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     landbits |= land << k;
                 }
             }
-            // the band's column totals, prefixed along longitude: what the bands below add to every entry
-            double carA = 0.0, carL = 0.0;
+            // the band's column sums (the counts already prefixed along longitude): what the bands below start from
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int c = ch * SB_WAVE + lane;
-                const double tA = sb_wave_scan_add_f64(colA[ch]) + carA, tL = sb_wave_scan_add_f64(colL[ch]) + carL;
-                if (c < W) { pA[wv * W + c] = tA; pL[wv * W + c] = tL; pC[wv * W + c] = colC[ch]; }
-                if (ch + 1 < NCH) { carA = sb_readlane_f64(tA, 63); carL = sb_readlane_f64(tL, 63); }
+                if (c < W) { pA[wv * W + c] = colA[ch]; pL[wv * W + c] = colL[ch]; pC[wv * W + c] = colC[ch]; }
             }
         }
         SB_T(2);                               // A1 compute
         lds_barrier();
         SB_T(3);                               // barrier 1
-        // the next tile's loads fly under A2 and A3 (and under the other workgroups' staging); the entry
-        // after it is fetched now
-        const int tile_after = next_tile;
-        if (PF && tile_after >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, tile_after, R);
+        // the next tile's loads fly under A2 and A3 (and under the other workgroups' staging); the list entry
+        // after it is fetched now, a whole tile before it is needed
+        const int tile_after = __builtin_amdgcn_readfirstlane(next_tile);
+        if (PF && tile_after >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile_after, wv, R);
         pos += G;
-        next_tile = pos + G < nactive ? job.tile_list[1 + pos + G] : -1;
+        next_tile = tile_after >= 0 ? job.tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
         // ---- A2: band cells -> list; finished tables ---------------------------------------------------
         int total;
         {
             const int pc = lane < TY ? __popcll(s_word[lane < TY ? lane : 0]) : 0;
             const int incl = sb_wave_scan_add(pc);
-            total = __shfl(incl, SB_WAVE - 1);
+            total = __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
             const int excl = incl - pc;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
@@ -329,22 +392,32 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
             }
         }
         {
-            double offA[NCH], offL[NCH];
-            int offC[NCH];
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int c = ch * SB_WAVE + lane < W ? ch * SB_WAVE + lane : 0;
-                offA[ch] = 0.0; offL[ch] = 0.0; offC[ch] = 0;
-                for (int b = 0; b < wv; ++b) {               // wave-uniform trip count; fixed order
-                    offA[ch] += pA[b * W + c];
-                    offL[ch] += pL[b * W + c];
-                    offC[ch] += pC[b * W + c];
-                }
-            }
+            // what the rows above this band sum to in every column: the running column prefix starts there, so
+            // the scan along longitude of a row's running sums is the finished table row
             double runA[NCH], runL[NCH];
             int runC[NCH];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) { runA[ch] = 0.0; runL[ch] = 0.0; runC[ch] = 0; }
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = ch * SB_WAVE + lane < W ? ch * SB_WAVE + lane : 0;
+                runA[ch] = 0.0; runL[ch] = 0.0; runC[ch] = 0;
+                if constexpr (NWV <= 8) {
+                    // every band's entry is read (one LDS round trip for all of them), the bands above are added
+                    // in their fixed order
+                    double xa[NWV - 1], xl[NWV - 1];
+                    int xc[NWV - 1];
+#pragma unroll
+                    for (int b = 0; b < NWV - 1; ++b) { xa[b] = pA[b * W + c]; xl[b] = pL[b * W + c]; xc[b] = pC[b * W + c]; }
+#pragma unroll
+                    for (int b = 0; b < NWV - 1; ++b)
+                        if (b < wv) { runA[ch] += xa[b]; runL[ch] += xl[b]; runC[ch] += xc[b]; }     // wave-uniform condition
+                } else {
+                    for (int b = 0; b < wv; ++b) {               // scalar trip count; fixed order
+                        runA[ch] += pA[b * W + c];
+                        runL[ch] += pL[b * W + c];
+                        runC[ch] += pC[b * W + c];
+                    }
+                }
+            }
 #pragma unroll
             for (int ri = 0; ri < RPW; ++ri) {
                 const int r = wv * RPW + ri;
@@ -360,12 +433,12 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     runL[ch] += land ? d[k] : 0.0;
                     runC[ch] += (int)(carryC + (unsigned)__popcll(lm & le_mask));
                     carryC += (unsigned)__popcll(lm);
-                    const double vA = sb_wave_scan_add_f64(runA[ch]) + carA, vL = sb_wave_scan_add_f64(runL[ch]) + carL;
+                    const double vA = ((THC_SKIP & 2) ? runA[ch] : sb_wave_scan_add_f64(runA[ch])) + carA, vL = ((THC_SKIP & 2) ? runL[ch] : sb_wave_scan_add_f64(runL[ch])) + carL;
                     if (c < W) {
                         const int o = (r + 1) * P + c + 1;
-                        sA[o] = vA + offA[ch];
-                        sL[o] = vL + offL[ch];
-                        sC[o] = (unsigned short)(runC[ch] + offC[ch]);
+                        sA[o] = vA;
+                        sL[o] = vL;
+                        sC[(r + 1) * PC + c + 1] = (unsigned short)runC[ch];
                     }
                     if (ch + 1 < NCH) { carA = sb_readlane_f64(vA, 63); carL = sb_readlane_f64(vL, 63); }
                 }
@@ -379,9 +452,10 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
         // the first is used, so a cell costs three LDS round trips (two for the radius, one for the sums).
         // QI list entries of a thread go through the rounds together (all of them while a SIMD holds only two
         // waves; one at a time at four waves per SIMD, where the other waves cover the round trips and the
-        // register budget is half).
+        // register budget is half).  Without ghost-cell limits (every boundary rule but SB_BND_HALO) the radii of
+        // a round are constants, and so are the table offsets of its sixteen / 4 (STEP - 1) reads.
         {
-            constexpr int QI = NT >= 1024 ? 1 : CPT;
+            constexpr int QI = THC_QI > 0 ? (THC_QI < CPT ? THC_QI : CPT) : (NT >= 1024 ? 1 : CPT);
             int nnmax = 0;
             unsigned slow = 0;                   // bit q: list entry q takes the global-memory path
             int ccall[CPT];
@@ -390,12 +464,13 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                 const int i = tid + q * NT;
                 ccall[q] = i < total ? (int)s_cell[i] : -1;
             }
+            const bool limited = g.bnd == BND_HALO;          // wave-uniform
 #pragma unroll
             for (int qb = 0; qb < CPT; qb += QI) {
-                int ccq[QI], limq[QI];
+                int ccq[QI], limq[QI], baseq[QI], basec[QI];
                 bool validq[QI];
                 SbCellState<T> cst[QI];
-                unsigned short t1[QI][4][4];                 // round 1: four corners of four squares
+                int nl1[QI][4];                              // round 1: land-side count of four squares
 #pragma unroll
                 for (int j = 0; j < QI; ++j) {
                     const int q = qb + j;
@@ -404,49 +479,56 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     const int lx = ccq[j] & 63, ly = ccq[j] >> 6;
                     const int x = x0 + lx, y = y0 + ly;
                     int lim = H;
-                    if (g.bnd == BND_HALO)                       // wave-uniform
-                        lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
+                    if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
                     limq[j] = lim;
                     if constexpr (!WF) {
                         cst[j] = SbCellState<T>{T(0), T(0), T(0), T(0)};
                         if (__ballot(validq[j]) != 0) cst[j] = sb_trigger_load<T>(job, (size_t)y * g.nx + x);   // clamped: a cell of the tile
                     }
-                    const int cx = lx + H, cy = ly + H;
+                    baseq[j] = (ly + H) * P + lx + H;        // the cell's own table entry (row cy, column cx)
+                    basec[j] = (ly + H) * PC + lx + H;       // ... in the count table
                     const int limc = max(lim, 1);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int rad = min((k + 1) * STEP, limc);
-                        const int r0 = (cy - rad) * P, r1 = (cy + rad + 1) * P, a0 = cx - rad, a1 = cx + rad + 1;
-                        t1[j][k][0] = sC[r1 + a1]; t1[j][k][1] = sC[r0 + a1]; t1[j][k][2] = sC[r1 + a0]; t1[j][k][3] = sC[r0 + a0];
+                        // C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0), r0 = cy-rad, r1 = cy+rad+1, a0 = cx-rad, a1 = cx+rad+1
+                        int rad = (k + 1) * STEP;
+                        if (limited) rad = min(rad, limc);
+                        const unsigned short *t = sC + basec[j];
+                        if (THC_SKIP & 4) nl1[j][k] = k + 1; else
+                        nl1[j][k] = (int)t[(rad + 1) * (PC + 1)] - (int)t[-rad * PC + rad + 1] - (int)t[(rad + 1) * PC - rad] + (int)t[-rad * (PC + 1)];
                     }
                 }
-                int loq[QI], hiq[QI], nlhi[QI];
+                int loq[QI], hiq[QI], nlhi[QI], nl2[QI][STEP > 1 ? STEP - 1 : 1];
                 bool fndq[QI];
-                unsigned short t2[QI][STEP > 1 ? STEP - 1 : 1][4];
 #pragma unroll
                 for (int j = 0; j < QI; ++j) {
                     const int limc = max(limq[j], 1);
                     // the smallest of the four squares that is mixed brackets the radius from above, the largest
                     // that is not from below
-                    int lo = 1, hi = limc, nl_hi = 0;
+                    int lo = 1, hi = limited ? limc : H, nl_hi = 0;
                     bool got = false;
 #pragma unroll
                     for (int k = 3; k >= 0; --k) {
-                        const int rad = min((k + 1) * STEP, limc);
-                        const int nl = (int)t1[j][k][0] - (int)t1[j][k][1] - (int)t1[j][k][2] + (int)t1[j][k][3];
+                        int rad = (k + 1) * STEP;
+                        if (limited) rad = min(rad, limc);
+                        const int nl = nl1[j][k];
                         const bool mixed = nl > 0 && nl < (2 * rad + 1) * (2 * rad + 1);
                         if (mixed) { hi = rad; nl_hi = nl; got = true; }
                         else if (rad < hi) lo = max(lo, rad + 1);
                     }
                     fndq[j] = validq[j] && limq[j] >= 1 && got;
-                    if (!got) { lo = limc; hi = limc; }
+                    // nothing found: probe below the widest square all the same (in bounds, results unused)
+                    if (!got) { hi = limited ? limc : H; lo = max(1, hi - (STEP - 1)); }
                     loq[j] = lo; hiq[j] = hi; nlhi[j] = nl_hi;
-                    const int lx = ccq[j] & 63, ly = ccq[j] >> 6, cx = lx + H, cy = ly + H;
+                    // rad = lo + m: the four corners move by constant strides from the corners of radius lo
+                    const unsigned short *t11 = sC + basec[j] + (lo + 1) * (PC + 1), *t01 = sC + basec[j] - lo * PC + lo + 1,
+                                         *t10 = sC + basec[j] + (lo + 1) * PC - lo, *t00 = sC + basec[j] - lo * (PC + 1);
 #pragma unroll
                     for (int m = 0; m < STEP - 1; ++m) {
-                        const int rad = min(lo + m, hi);
-                        const int r0 = (cy - rad) * P, r1 = (cy + rad + 1) * P, a0 = cx - rad, a1 = cx + rad + 1;
-                        t2[j][m][0] = sC[r1 + a1]; t2[j][m][1] = sC[r0 + a1]; t2[j][m][2] = sC[r1 + a0]; t2[j][m][3] = sC[r0 + a0];
+                        if (THC_SKIP & 4) nl2[j][m] = m + 1; else
+                        if (!limited || lo + m <= hi)
+                            nl2[j][m] = (int)t11[m * (PC + 1)] - (int)t01[m * (1 - PC)] - (int)t10[m * (PC - 1)] + (int)t00[-m * (PC + 1)];
+                        else nl2[j][m] = 0;
                     }
                 }
                 int nnq[QI], nlq[QI];
@@ -457,15 +539,17 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     int nn = hiq[j], nl = nlhi[j];
 #pragma unroll
                     for (int m = STEP - 2; m >= 0; --m) {
-                        const int rad = min(loq[j] + m, hiq[j]);
-                        const int c = (int)t2[j][m][0] - (int)t2[j][m][1] - (int)t2[j][m][2] + (int)t2[j][m][3];
-                        if (c > 0 && c < (2 * rad + 1) * (2 * rad + 1)) { nn = rad; nl = c; }
+                        const int rad = loq[j] + m;
+                        const int c = nl2[j][m];
+                        if (rad < hiq[j] && c > 0 && c < (2 * rad + 1) * (2 * rad + 1)) { nn = rad; nl = c; }
                     }
                     nnq[j] = nn; nlq[j] = nl;
-                    const int lx = ccq[j] & 63, ly = ccq[j] >> 6, cx = lx + H, cy = ly + H;
-                    const int r0 = (cy - nn) * P, r1 = (cy + nn + 1) * P, a0 = cx - nn, a1 = cx + nn + 1;
-                    sums[j][0] = sL[r1 + a1]; sums[j][1] = sL[r0 + a1]; sums[j][2] = sL[r1 + a0]; sums[j][3] = sL[r0 + a0];
-                    sums[j][4] = sA[r1 + a1]; sums[j][5] = sA[r0 + a1]; sums[j][6] = sA[r1 + a0]; sums[j][7] = sA[r0 + a0];
+                    const int b = baseq[j];
+                    const int o11 = b + (nn + 1) * (P + 1), o01 = b - nn * P + nn + 1, o10 = b + (nn + 1) * P - nn, o00 = b - nn * (P + 1);
+                    if (THC_SKIP & 8) { for (int e = 0; e < 8; ++e) sums[j][e] = (double)(o11 + e); } else {
+                    sums[j][0] = sL[o11]; sums[j][1] = sL[o01]; sums[j][2] = sL[o10]; sums[j][3] = sL[o00];
+                    sums[j][4] = sA[o11]; sums[j][5] = sA[o01]; sums[j][6] = sA[o10]; sums[j][7] = sA[o00]; }
+                    const int cx = (ccq[j] & 63) + H, cy = (ccq[j] >> 6) + H;
                     ownw[j] = s_land[par][cy * NCH + (cx >> 6)];
                 }
 #pragma unroll
@@ -476,7 +560,8 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     const int nn = nnq[j], area = (2 * nn + 1) * (2 * nn + 1);
                     const double RL = (sums[j][0] - sums[j][1]) - (sums[j][2] - sums[j][3]);
                     const double RA = (sums[j][4] - sums[j][5]) - (sums[j][6] - sums[j][7]);
-                    const T contrast = (T)(RL / (double)nlq[j] - (RA - RL) / (double)(area - nlq[j]));
+                    // the two means by reciprocals of the (small, exact) counts: within an ulp of the quotients
+                    const T contrast = (T)(RL * sb_inv((double)nlq[j]) - (RA - RL) * sb_inv((double)(area - nlq[j])));
                     // the cell's own class: the table's centre, except that the f2py boundary rule maps the
                     // centre of the window at the last longitude to column 1   ref :182-186, seabreeze_diag_python.f90:202
                     bool own = (ownw[j] >> (cx & 63)) & 1ull;
@@ -515,9 +600,8 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                 }
             }
             // per-tile largest radius (diagnostic; reduced lazily by sb_last_counters); the flag k_scan raised is 1
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nnmax = max(nnmax, __shfl_xor(nnmax, off));
-            if (lane == 0 && nnmax > 1) atomicMax(&job.tile_nnmax[tile], nnmax);
+            nnmax = sb_wave_max_to_last(nnmax);
+            if (lane == SB_WAVE - 1 && nnmax > 1) atomicMax(&job.tile_nnmax[tile], nnmax);
         }
         // no barrier here: the next tile's A1 writes s_word and the band totals (last read before the barrier
         // above) and the other s_land buffer; its first barrier stands before any table or list write

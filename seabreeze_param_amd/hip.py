@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEABREEZE_HIP_LIB", os.path.join(_HERE, "libseabreeze_hip.so"))
 
 SB_BND_WRAPPER, SB_BND_GLOBAL, SB_BND_HALO = 0, 1, 2
+SB_UM_THETA_TO_T0, SB_UM_LEVEL_WALK = 1, 2
 
 _SFX = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 _CT = {np.dtype(np.float32): C.c_float, np.dtype(np.float64): C.c_double}
@@ -142,6 +143,25 @@ class Context:
                 _p(ws), _p(wd), _p(thc), _p(sb_con), C.byref(tunables) if tunables is not None else None)
         self._chk(rc, "sb_seabreeze_diag")
         return sb_con
+
+    def seabreeze_diag_um(self, timestep, tn, p, u, v, theta, z, sigma, mask, ws, wd, thc, sb_con,
+                          halo_s, halo_l, flags=0):
+        """UM vn10.7 layout and argument order (UM/vn10.7/sea_breeze_diag.F90:55-117): theta, z, sigma carry halo_s
+        ghost cells, mask halo_l >= halo_s; theta is overwritten with t0 under SB_UM_THETA_TO_T0.  Returns `error`."""
+        dt = np.dtype(ws.dtype)
+        sfx, ct = _SFX[dt], _CT[dt]
+        p = _host(p, dt); u = _host(u, dt); v = _host(v, dt)
+        z = _host(z, dt); sigma = _host(sigma, dt); mask = _host(mask, dt)
+        if theta.dtype != dt or not theta.flags.c_contiguous:
+            raise ValueError("theta must be a C-contiguous array of the working dtype (it may be overwritten)")
+        nz, ny, nx = p.shape if p.ndim == 3 else (0, 0, 0)
+        err = C.c_int(0)
+        fn = getattr(self.lib, f"sb_seabreeze_diag_um_{sfx}")
+        rc = fn(self.h, ct(timestep), C.c_int(tn), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(halo_s), C.c_int(halo_l),
+                _p(p), _p(u), _p(v), _p(theta), _p(z), _p(sigma), _p(mask), _p(ws), _p(wd), _p(thc), _p(sb_con),
+                C.c_int(flags), C.byref(err))
+        self._chk(rc, "sb_seabreeze_diag_um")
+        return err.value
 
     def diag(self, tn, p, z, std, theta, v, u, cdist, ws, wd, thc, output=None,
              target_plev=700.0, thresh_wind=11.0, thresh_winddir=90.0, thresh_windch=5.0,

@@ -86,6 +86,19 @@ def test_split_rows_and_ghost_fill():
         assert all(a[1] == b[0] for a, b in zip(sp, sp[1:]))
         sizes = [b - a for a, b in sp]
         assert max(sizes) - min(sizes) <= 1
+    # cuts by cost: contiguous, complete, no band thinner than the ghost frame, and better balanced than equal rows
+    st = synth.static_fields(256, 192)
+    band = (st.landfrac > 0) ^ np.roll(st.landfrac > 0, 3, axis=1)          # a clustered stand-in for the coastal band
+    cost = bands.row_cost(band, 56)
+    for w, hmin in ((2, 1), (4, 8), (8, 17)):
+        sp = bands.split_rows(192, w, cost=cost, min_rows=hmin)
+        assert sp[0][0] == 0 and sp[-1][1] == 192 and all(a[1] == b[0] for a, b in zip(sp, sp[1:]))
+        assert min(b - a for a, b in sp) >= hmin
+        worst = max(cost[a:b].sum() for a, b in sp)
+        worst_equal = max(cost[a:b].sum() for a, b in bands.split_rows(192, w))
+        assert worst <= worst_equal * 1.0001
+    with pytest.raises(ValueError):
+        bands.split_rows(10, 4, cost=np.ones(10), min_rows=3)
     nx, h = 10, 3
     core = np.arange(4 * nx, dtype=np.float64).reshape(4, nx)
     loc = np.zeros((4, nx + 2 * h))

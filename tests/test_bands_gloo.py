@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nx, ny, nz, h, tmpdir):
+def _worker(rank, world, port, nx, ny, nz, h, tmpdir, balanced):
     sys.path.insert(0, ROOT)
     from oracle.pyoracle import Oracle
     from seabreeze_param_amd import bands, synth
@@ -38,7 +38,9 @@ def _worker(rank, world, port, nx, ny, nz, h, tmpdir):
         coast = orc.get_edges(st.landfrac, st.icefrac)
         cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=900.0, kwin=h - 1)
         cdist[np.abs(cdist) > 180.0] = 12000.0
-        r0, r1 = bands.split_rows(ny, world)[rank]
+        # equal row counts, or bands cut by cost (unequal heights): every rank derives the same cuts
+        cost = bands.row_cost(np.abs(cdist) <= 180.0, nz) if balanced else None
+        r0, r1 = bands.split_rows(ny, world, cost=cost, min_rows=h)[rank]
         nyl = r1 - r0
 
         def halo_field(full):
@@ -77,8 +79,8 @@ def _worker(rank, world, port, nx, ny, nz, h, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_band_decomposition_reproduces_global(tmp_path, world):
+@pytest.mark.parametrize("world,balanced", [(2, False), (3, False), (2, True), (3, True)])
+def test_band_decomposition_reproduces_global(tmp_path, world, balanced):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 96, 72, 3, 6, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 96, 72, 3, 6, str(tmp_path), balanced), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

@@ -242,6 +242,66 @@ def test_halo_mode_matches_oracle(hipctx, oracles, tile_rows):
             _assert_close64(a, b, f"halo tn={tn} {nm}")
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("flags", [0, hip.SB_UM_LEVEL_WALK, hip.SB_UM_THETA_TO_T0 | hip.SB_UM_LEVEL_WALK])
+def test_um_layout_halo2(hipctx, oracles, prec, flags):
+    """BASELINE configs[4]'s layout: the UM vn10.7 bounds (UM/vn10.7/sea_breeze_diag.F90:66-117) with a small halo
+    of 2 cells around theta, z, sigma and a large halo of 5 around mask, the UM argument order, the `error` argument,
+    the in-place theta <- t0 (:210-211) and the upward level walk (:265-274), against the oracle's raw-index
+    (BND_HALO) flavour with the same level rule.  The UM file cannot be compiled here: parity unpinned by nature."""
+    nx, ny, nz, hs, hl = 120, 70, 6, 2, 5
+    dt = np.float64 if prec == 8 else np.float32
+    orc = oracles[prec]
+    st = synth.static_fields(nx + 2 * hl, ny + 2 * hl, dt)                 # a bigger field whose rim serves as ghosts
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cd_l = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=9000.0, kwin=1)    # radii stay within 2 cells
+    cd_l = np.where(np.abs(cd_l) < 12000.0, np.sign(cd_l) * np.minimum(np.abs(cd_l), 179.0), cd_l).astype(dt)
+    inner = lambda a, h: np.ascontiguousarray(a[hl - h:a.shape[0] - (hl - h), hl - h:a.shape[1] - (hl - h)])
+    core = (slice(hl, hl + ny), slice(hl, hl + nx))
+    p = synth.pressure_3d(st, nz, dt)[:, core[0], core[1]].copy()
+    # every third column: level 1 is nearer 700 hPa than level 2 but level 4 is the nearest of all -- the UM walk
+    # stops at level 1, the generic rule finds level 4
+    p[0, :, ::3] = 76000.0
+    p[1, :, ::3] = 90000.0
+    p[3, :, ::3] = 70500.0
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    rule = 1 if flags & hip.SB_UM_LEVEL_WALK else 0
+    levels_differ = False
+    for tn in range(1, 4):
+        th_l = synth.theta_step(st, tn, dt)
+        u, v = (a[:, core[0], core[1]].copy() for a in synth.wind_step(st, nz, tn, dt))
+        th_s, z_s, sg_s = inner(th_l, hs), inner(st.z, hs), inner(st.sigma, hs)
+        orc.seabreeze_diag(7200.0, tn, p, u, v, th_s, inner(cd_l, hs), z_s, sg_s, *so, halo=hs, bnd=2, level_rule=rule)
+        theta_arg = th_s.copy()
+        err = hipctx.seabreeze_diag_um(7200.0, tn, p, u, v, theta_arg, z_s, sg_s, cd_l, *sh, halo_s=hs, halo_l=hl, flags=flags)
+        assert err == 0
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+            if prec == 8:
+                _assert_close64(a, b, f"UM layout flags={flags} tn={tn} {nm}")
+            elif nm in ("ws", "wd"):
+                assert relerr(a, b, floor=1e-1) < 2e-5, (nm, tn)
+            elif nm == "thc":
+                assert np.max(np.abs(a - b)) < 2e-3, tn
+        if flags & hip.SB_UM_THETA_TO_T0:
+            sd, r = orc.sigmoid_scalars(inner(st.sigma, 0))
+            t0 = th_s - (dt(-0.0060956) * z_s) * (1 / (1 + np.exp(-dt(sd) * (sg_s - dt(r)))))
+            assert relerr(theta_arg, t0) < (1e-12 if prec == 8 else 2e-6)
+        else:
+            assert np.array_equal(theta_arg, th_s)
+    c = hipctx.last_counters()
+    assert c["one_class_cells"] == 0 and 1 <= c["max_radius"] <= hs
+    # the two level rules really differ on this input
+    s0, s1 = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    for s4, r_ in ((s0, 0), (s1, 1)):
+        orc.seabreeze_diag(7200.0, 1, p, u, v, th_s, inner(cd_l, hs), z_s, sg_s, *s4, halo=hs, bnd=2, level_rule=r_)
+    assert not np.array_equal(s0[0], s1[0])
+    # UM error semantics (:198-202): no levels -> error = 1, nothing touched
+    before = [a.copy() for a in sh]
+    err = hipctx.seabreeze_diag_um(7200.0, 5, np.zeros((0, ny, nx), dt), np.zeros((0, ny, nx), dt), np.zeros((0, ny, nx), dt),
+                                   th_s.copy(), z_s, sg_s, cd_l, *sh, halo_s=hs, halo_l=hl, flags=flags)
+    assert err == 1 and all(np.array_equal(a, b) for a, b in zip(sh, before))
+
+
 def test_search_radius_beyond_lds_halo(hipctx, oracles):
     """Radius hint 8 but radii up to ~13: cells past the LDS halo take the global-memory path
     and must give the same numbers."""
