@@ -22,6 +22,9 @@
 #ifndef THC_SKIP
 #define THC_SKIP 0                // diagnostic builds only: bit 0 no sigmoid, 1 no scans, 2 no radius probes, 3 no sums, 4 no prefetch loads
 #endif
+#ifndef THC_SEARCH
+#define THC_SEARCH 1               // radius search on the count table: 0 two rounds of independent probes, 1 bisection
+#endif
 #ifndef THC_PC16
 #define THC_PC16 1                 // count table rows 16 banks apart (0: the pitch of the fp64 tables)
 #endif
@@ -151,21 +154,31 @@ struct ThcRegs {
     T c0;                          // the tile's offset
 };
 
+// The loads of a tile come in two parts so that the second can be spread over the work of the tile before it:
+// thc_issue_begin works out the lane's column offsets and issues the few loads that belong to the tile as a whole,
+// thc_issue_row issues the loads of one of the wave's rows.  (Pushing all 41 loads of a thread through the
+// texture-address unit in one burst takes 2.6 k cycles per tile -- 512 bytes per wave instruction at 64 bytes per
+// clock, eight waves -- during which the waves stand at their load instructions.)
+template <int NCH>
+struct ThcCols {
+    unsigned colb[NCH], clsb[NCH];               // byte offsets of the lane's column: in a field row, in a row of the bit plane
+    int y0;                                      // first interior row of the tile (wave-uniform)
+};
+
 template <typename T, int TX, int TY, int H, int NT, bool FLY, int RPW, int NCH>
-__device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<FLY> &B, int tile, int wvu,
-                                          ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+__device__ __forceinline__ void thc_issue_begin(const DiagJob<T> &job, const ThcBufs<FLY> &B, int tile,
+                                                ThcRegs<T, RPW * NCH, NCH, FLY> &R, ThcCols<NCH> &C) {
     constexpr int W = TX + 2 * H;
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int ntx = job.thc_ntx;
     const int ty = tile / ntx;                   // tile is wave-uniform (scalar division)
     const int x0 = (tile - ty * ntx) * TX, y0 = ty * TY;
+    C.y0 = y0;
     int X, Y;
     sb_map_cell(g, x0, y0, X, Y);
-    const unsigned unxh = (unsigned)g.nxh;
-    const unsigned i00 = (unsigned)Y * unxh + (unsigned)X;
+    const unsigned i00 = (unsigned)Y * (unsigned)g.nxh + (unsigned)X;
     const bool fastx = g.nx > W + 2;             // one conditional add wraps every column of the tile
-    unsigned colb[NCH], clsb[NCH];               // byte offsets of the lane's column: in a field row, in a row of the bit plane
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = ch * SB_WAVE + lane;
@@ -185,27 +198,10 @@ __device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<F
         }
         R.xcol[ch] = ok ? Xc : -1;
         const unsigned xc = ok ? (unsigned)Xc : 0u;              // every load is unconditional, from a clamped address
-        colb[ch] = xc * (unsigned)sizeof(T);
-        clsb[ch] = (xc >> 5) * 4u;
+        C.colb[ch] = xc * (unsigned)sizeof(T);
+        C.clsb[ch] = (xc >> 5) * 4u;
     }
     R.rowok = 0;
-#pragma unroll
-    for (int ri = 0; ri < RPW; ++ri) {
-        const int ys = y0 - H + wvu * RPW + ri;  // scalar: the wave's row
-        int Yr;
-        bool rowok = true;
-        if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
-        else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-        const unsigned rowb = (unsigned)Yr * unxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
-        R.rowok |= (rowok ? 1u : 0u) << ri;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int k = ri * NCH + ch;
-            R.th[k] = sb_buf_ld<T>(B.th, colb[ch], rowb);
-            if constexpr (FLY) { R.zz[k] = sb_buf_ld<T>(B.zz, colb[ch], rowb); R.sg[k] = sb_buf_ld<T>(B.sg, colb[ch], rowb); }
-            R.lw[k] = __builtin_amdgcn_raw_buffer_load_b32(B.cls, clsb[ch], wordb, 0);
-        }
-    }
     // the tile's offset -- any common value conditions the sums, and theta at the tile origin needs
     // no sigmoid -- and the band words
     R.c0 = sb_buf_ld<T>(B.th, 0u, i00 * (unsigned)sizeof(T));
@@ -217,6 +213,35 @@ __device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<F
         R.bw1 = row[wi + 1 < g.nw ? wi + 1 : wi];
         R.bsh = have ? (Xb & 63) + (wi + 1 < g.nw ? 0 : 64) : -1;      // +64: there is no second word
     }
+}
+
+template <typename T, int H, bool FLY, int RPW, int NCH>
+__device__ __forceinline__ void thc_issue_row(const DiagJob<T> &job, const ThcBufs<FLY> &B, const ThcCols<NCH> &C, int wvu,
+                                              int ri, ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+    const Geo g = job.g;
+    const int ys = C.y0 - H + wvu * RPW + ri;    // scalar: the wave's row
+    int Yr;
+    bool rowok = true;
+    if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
+    else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+    const unsigned rowb = (unsigned)Yr * (unsigned)g.nxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
+    R.rowok |= (rowok ? 1u : 0u) << ri;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int k = ri * NCH + ch;
+        R.th[k] = sb_buf_ld<T>(B.th, C.colb[ch], rowb);
+        if constexpr (FLY) { R.zz[k] = sb_buf_ld<T>(B.zz, C.colb[ch], rowb); R.sg[k] = sb_buf_ld<T>(B.sg, C.colb[ch], rowb); }
+        R.lw[k] = __builtin_amdgcn_raw_buffer_load_b32(B.cls, C.clsb[ch], wordb, 0);
+    }
+}
+
+template <typename T, int TX, int TY, int H, int NT, bool FLY, int RPW, int NCH>
+__device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<FLY> &B, int tile, int wvu,
+                                          ThcRegs<T, RPW * NCH, NCH, FLY> &R) {
+    ThcCols<NCH> C;
+    thc_issue_begin<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, R, C);
+#pragma unroll
+    for (int ri = 0; ri < RPW; ++ri) thc_issue_row<T, H, FLY, RPW, NCH>(job, B, C, wvu, ri, R);
 }
 
 // reciprocal of a small positive integer held in a double: v_rcp_f64 and two Newton steps (within an ulp of 1/n)
@@ -239,7 +264,7 @@ __device__ __forceinline__ int sb_wave_max_to_last(int v) {
 }
 
 template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF>     // WF: k_wind applies the update (job.wind_final)
-__global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
+__global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, const T *__restrict__ stats, int G, DiagJob<T> job) {
     constexpr int NWV = NT / SB_WAVE;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
     // The count table has a pitch of its own: its 2-byte entries make consecutive rows of pitch W + 1 (65 entries =
@@ -284,11 +309,16 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     // cold caches, so what counts is the number of dependent round trips: kernel arguments -> {this workgroup's
     // first two list entries, the sigmoid scalars} -> the first tile's inputs.  The list ends in -1 entries, so the
     // count of active tiles is not needed.
-    const int G = (int)gridDim.x;
-    int pos = (int)blockIdx.x;
-    const int cand0 = job.tile_list[1 + pos], cand1 = job.tile_list[1 + pos + G];
+    int pos = (int)blockIdx.x;                 // G = gridDim.x, as an argument: the launch-size block is one more load
+    // (the two pointers the first round trip needs are the kernel's leading arguments: the hardware preloads them
+    // into scalar registers with the launch, -mllvm -amdgpu-kernarg-preload-count, so that round trip does not
+    // wait for a load of the argument block)
+    // every line of the argument block is touched by the first batch of scalar loads (a later first touch would be
+    // one more cold round trip): the two pointers the compiler would otherwise fetch where they are first used
+    asm volatile("" ::"s"(job.tile_nnmax), "s"(job.counters));
+    const int cand0 = tile_list[1 + pos], cand1 = tile_list[1 + pos + G];
     T sd = T(0), rr = T(0);
-    if constexpr (FLY) { sd = job.stats[0]; rr = job.stats[1]; }
+    if constexpr (FLY) { sd = stats[0]; rr = stats[1]; }
     const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
     ThcBufs<FLY> B;
     B.th = sb_make_rsrc(FLY ? (const void *)job.theta : (const void *)job.t0, fbytes);
@@ -297,10 +327,19 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
     B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
     for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * PC] = 0; }
     for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+#ifdef SB_STAMPS
+    acc[11] = clock64() - t_last;              // LDS borders zeroed (no load waited for yet)
+#endif
     int tile = __builtin_amdgcn_readfirstlane(cand0);
     int next_tile = __builtin_amdgcn_readfirstlane(cand1);
+#ifdef SB_STAMPS
+    acc[12] = clock64() - t_last;              // first list entries and scalars have arrived
+#endif
     ThcRegs<T, NC, NCH, FLY> R;
     if (PF && tile >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, wv, R);
+#ifdef SB_STAMPS
+    acc[13] = clock64() - t_last;              // first tile's loads issued
+#endif
     __syncthreads();
     SB_T(0);                                   // prologue
 
@@ -371,9 +410,10 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
         // the next tile's loads fly under A2 and A3 (and under the other workgroups' staging); the list entry
         // after it is fetched now, a whole tile before it is needed
         const int tile_after = __builtin_amdgcn_readfirstlane(next_tile);
-        if (PF && tile_after >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile_after, wv, R);
+        ThcCols<NCH> Cn;
+        if (PF && tile_after >= 0) thc_issue_begin<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile_after, R, Cn);
         pos += G;
-        next_tile = tile_after >= 0 ? job.tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
+        next_tile = tile_after >= 0 ? tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
         // ---- A2: band cells -> list; finished tables ---------------------------------------------------
         int total;
         {
@@ -442,6 +482,8 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     }
                     if (ch + 1 < NCH) { carA = sb_readlane_f64(vA, 63); carL = sb_readlane_f64(vL, 63); }
                 }
+                // the next tile's loads of this row go out between the rows' scans, not in one burst
+                if (PF && tile_after >= 0) thc_issue_row<T, H, FLY, RPW, NCH>(job, B, Cn, wv, ri, R);
             }
         }
         SB_T(4);                               // A2 (issue of the next tile, list, tables)
@@ -489,7 +531,7 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                     basec[j] = (ly + H) * PC + lx + H;       // ... in the count table
                     const int limc = max(lim, 1);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = (THC_SEARCH == 1 ? 3 : 0); k < 4; ++k) {
                         // C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0), r0 = cy-rad, r1 = cy+rad+1, a0 = cx-rad, a1 = cx+rad+1
                         int rad = (k + 1) * STEP;
                         if (limited) rad = min(rad, limc);
@@ -500,6 +542,42 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                 }
                 int loq[QI], hiq[QI], nlhi[QI], nl2[QI][STEP > 1 ? STEP - 1 : 1];
                 bool fndq[QI];
+                if constexpr (THC_SEARCH == 1) {
+                    // bisection on the count table: 4 reads per probe, the widest square first, then ITER halvings
+                    // (20 reads for a halo of 16 against the 28 of the two-round form, five dependent rounds against two;
+                    // the rounds of the QI list entries overlap)
+                    constexpr int ITER = (H <= 2 ? 1 : H <= 4 ? 2 : H <= 8 ? 3 : H <= 16 ? 4 : 5);
+                    auto count = [&](int j, int rad) {
+                        const unsigned short *t = sC + basec[j];
+                        const int q = rad * (PC + 1);
+                        return (int)t[q + PC + 1] - (int)t[-q + 2 * rad + 1] - (int)t[q + PC - 2 * rad] + (int)t[-q];
+                    };
+#pragma unroll
+                    for (int j = 0; j < QI; ++j) {
+                        const int limc = max(limq[j], 1);
+                        const int nl = nl1[j][3];                // the square of radius min(H, lim)
+                        const bool got = nl > 0 && nl < (2 * limc + 1) * (2 * limc + 1);
+                        fndq[j] = validq[j] && limq[j] >= 1 && got;
+                        loq[j] = got ? 1 : limc; hiq[j] = limc; nlhi[j] = nl;
+                    }
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        int nlm[QI];
+#pragma unroll
+                        for (int j = 0; j < QI; ++j) nlm[j] = count(j, (loq[j] + hiq[j]) >> 1);
+#pragma unroll
+                        for (int j = 0; j < QI; ++j) {
+                            const int mid = (loq[j] + hiq[j]) >> 1;
+                            const bool act = loq[j] < hiq[j], ok = nlm[j] > 0 && nlm[j] < (2 * mid + 1) * (2 * mid + 1);
+                            nlhi[j] = (act && ok) ? nlm[j] : nlhi[j];
+                            hiq[j] = (act && ok) ? mid : hiq[j];
+                            loq[j] = (act && !ok) ? mid + 1 : loq[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < QI; ++j)
+                        for (int m = 0; m < STEP - 1; ++m) nl2[j][m] = 0;      // no second round: hi is the radius
+                } else {
 #pragma unroll
                 for (int j = 0; j < QI; ++j) {
                     const int limc = max(limq[j], 1);
@@ -531,6 +609,7 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                         else nl2[j][m] = 0;
                     }
                 }
+                }
                 int nnq[QI], nlq[QI];
                 double sums[QI][8];
                 uint64_t ownw[QI];
@@ -538,7 +617,7 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
                 for (int j = 0; j < QI; ++j) {
                     int nn = hiq[j], nl = nlhi[j];
 #pragma unroll
-                    for (int m = STEP - 2; m >= 0; --m) {
+                    for (int m = (THC_SEARCH == 1 ? -1 : STEP - 2); m >= 0; --m) {
                         const int rad = loq[j] + m;
                         const int c = nl2[j][m];
                         if (rad < hiq[j] && c > 0 && c < (2 * rad + 1) * (2 * rad + 1)) { nn = rad; nl = c; }
@@ -621,10 +700,10 @@ __global__ __launch_bounds__(NT) void k_thc3(DiagJob<T> job) {
 template <typename T, int TX, int TY, int H, int NT>
 static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
     const dim3 gr(nblocks), bl(NT);
-    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, job);
-    else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, job);
-    else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true>), gr, bl, 0, st, job);
-    else hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false>), gr, bl, 0, st, job);
+    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
 }
 
 template <typename T>

@@ -43,4 +43,5 @@ for i, nm in enumerate(names):
 print(f"  total cycles per workgroup mean {tot.mean():.0f} max {tot.max()}; wall (10 ns ticks) start spread "
       f"{s[:, 9].max() - s[:, 9].min()}, life mean {np.mean(s[:, 10] - s[:, 9]):.0f} max {np.max(s[:, 10] - s[:, 9])}, "
       f"kernel span {s[:, 10].max() - s[:, 9].min()}")
+print(f"  prologue split (cycles since kernel start, mean): borders zeroed {s[:, 11].mean():.0f}, list entries + scalars arrived {s[:, 12].mean():.0f}, first tile issued {s[:, 13].mean():.0f}, barrier passed {s[:, 0].mean():.0f}")
 print(ctx.last_counters())
