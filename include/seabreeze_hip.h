@@ -90,6 +90,17 @@ int  sb_set_tile_rows(sb_ctx *ctx, int rows);
 /* Threads of the contrast kernel's workgroups for halos up to 16: 512 (8 waves of up to 256 registers, the
    default) or 1024 (16 waves of up to 128).  A tuning and test knob: results never depend on it.       */
 int  sb_set_thc_threads(sb_ctx *ctx, int threads);
+/* Opt-in, off by default: the caller states that sigma (the sub-grid orography deviation, an ancillary that a
+   host model reads once; ref: generic/sea_breeze_diag.f90:159-166 recomputes its mean and deviation every
+   call) does not change between calls.  The first complete diag / band step after the switch forms the
+   statistics as usual; later calls that pass the same array (address, shape, ghost width, precision) reuse its
+   sigmoid scalars: k_scan stops reading sigma (one of its three planes) and a band step drops the moments
+   all-gather and the merge.  Results are those of the default path as long as the statement holds; any other
+   sigma array, or switching the option again, forms the statistics anew.                                  */
+int  sb_set_static_sigma(sb_ctx *ctx, int on);
+/* What the last diag call or band step enqueued on this rank: [0] kernel launches, [1] RCCL operations (sends,
+   receives, all-gathers), [2] RCCL groups, [3] device-to-device copies.  No synchronisation.               */
+int  sb_last_step_report(sb_ctx *ctx, int report[4]);
 /* Counters of the last diag call: [0] band cells, [1] cells that left the LDS path,
    [2] cells whose search found only one class (result NaN; the reference loops
    forever there, ref: generic/sea_breeze_diag.f90:191-214), [3] max radius used.

@@ -98,11 +98,16 @@ class BandRunner:
     """Owns one rank's device-resident fields and runs seabreeze_diag steps on them."""
 
     def __init__(self, ctx: _hip.Context, torch, dist, rank: int, world: int, nx: int, ny: int, nz: int,
-                 halo: int, dtype=np.float64, comm: str = "torch", rows=None):
+                 halo: int, dtype=np.float64, comm: str = "torch", rows=None, static_sigma: bool = False):
         """comm="torch": ghost rows and moments travel through torch.distributed (`dist`, any backend);
         comm="native": through the library's own RCCL communicator (ctx.comm_init must have run):
-        ncclSend/ncclRecv + ncclAllGather enqueued on the compute stream by two C-ABI calls."""
+        ncclSend/ncclRecv + ncclAllGather enqueued on the compute stream by two C-ABI calls.
+        static_sigma=True (opt-in, sb_set_static_sigma): sigma's statistics are formed and gathered in the first
+        step only; later steps run without the moments pass, the all-gather and the merge."""
         assert comm in ("torch", "native")
+        self.static_sigma = bool(static_sigma)
+        self._stats_done = False
+        ctx.set_static_sigma(self.static_sigma)
         self.comm = comm
         self.ctx, self.torch, self.dist = ctx, torch, dist
         self.rank, self.world = rank, world
@@ -172,12 +177,14 @@ class BandRunner:
                                              self.thc.data_ptr(), self.sb_con.data_ptr(), stream)
             return
         if self.world > 1:
-            self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
-                                       self.mom.data_ptr(), stream)
-            if self.comm == "native":
-                self.ctx.allgather_moments_dev(self.mom.data_ptr(), self.gath.data_ptr(), stream)
-            else:
-                self.dist.all_gather_into_tensor(self.gath, self.mom)
+            if not (self.static_sigma and self._stats_done):
+                self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
+                                           self.mom.data_ptr(), stream)
+                if self.comm == "native":
+                    self.ctx.allgather_moments_dev(self.mom.data_ptr(), self.gath.data_ptr(), stream)
+                else:
+                    self.dist.all_gather_into_tensor(self.gath, self.mom)
+                self._stats_done = True
             self._fill_ghosts(s["theta"])               # theta changes every step
         self.ctx.seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h, self.bnd,
                                     s["p"].data_ptr(), s["u"].data_ptr(), s["v"].data_ptr(),

@@ -52,6 +52,15 @@ struct sb_ctx {
     int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc2 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
     int thc_nt = 512;           // threads of a k_thc3 workgroup (sb_set_tuning)
+    // opt-in: sigma does not change between calls (sb_set_static_sigma): its statistics are kept from the first
+    // complete call on the same array and k_scan stops reading it
+    int static_sigma = 0;
+    bool stats_valid = false;
+    int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
+    const void *stats_sigma = nullptr;
+    int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
+    // what the last diag / band step enqueued (sb_last_step_report)
+    int rep_launches = 0, rep_rccl = 0, rep_groups = 0, rep_copies = 0;
     // workspace (grow-only)
     DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps;
     int tiles_n = 0, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
@@ -129,6 +138,13 @@ int pick_halo(const sb_ctx *c) {
     if (r <= 16) return 16;
     if (r <= 24) return 24;
     return SB_MAX_LDS_HALO;
+}
+
+// sigma's statistics of an earlier complete call still stand (opt-in, same array, same shape)
+template <typename T>
+static bool reuse_stats(const sb_ctx *c, const T *sigma, int nx, int ny, int halo) {
+    return c->static_sigma && c->host_depth == 0 && c->stats_valid && c->stats_sigma == (const void *)sigma && c->stats_dims[0] == nx &&
+           c->stats_dims[1] == ny && c->stats_dims[2] == halo && c->stats_dims[3] == (int)sizeof(T);
 }
 
 // Prepare workspace + job; enqueue the kernels of one diag call.
@@ -215,8 +231,18 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.moments_out = (phases & 1) ? c->band_moments_out : nullptr;
     lc.moments_event = (phases & 1) ? c->band_moments_event : nullptr;
     lc.phases = phases;
+    lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
+    int launched = 0;
+    lc.launches = &launched;
+    if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
     HIPCHK(c, sb_launch_diag<T>(job, H, lc));
+    c->rep_launches += launched;
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
+    if (c->static_sigma && c->host_depth == 0 && !lc.reuse_stats) {
+        c->stats_valid = true;
+        c->stats_sigma = (const void *)job.sigma;
+        c->stats_dims[0] = g.nx; c->stats_dims[1] = g.ny; c->stats_dims[2] = g.h; c->stats_dims[3] = (int)sizeof(T);
+    }
     c->last_flags = flags_now;
     c->flag_parity = 1 - c->flag_parity;
     c->last_g = g;
@@ -295,6 +321,9 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     if (!c->ev_mom) HIPCHK(c, hipEventCreateWithFlags(&c->ev_mom, hipEventDisableTiming));
     if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
     double *mine = (double *)c->band_mom.p, *gath = mine + 5;
+    // static sigma (opt-in): the scalars of the first step stand, no moments, no all-gather, no merge
+    const bool reuse = reuse_stats<T>(c, sigma, nx, ny, halo);
+    c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;
     // fork: everything that talks to the neighbours goes to the second stream.  The ghost rows of theta
     // need nothing from this step, so they travel first, while this band's sigma moments are formed on
     // the caller's stream; the all-gather follows them (every rank issues the two in this order).
@@ -313,11 +342,11 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
                                thc, sb_con, tun, (void *)st, 1);
     c->band_moments_out = nullptr;
     c->band_moments_event = nullptr;
-    if (!rc) {
+    if (!rc && !reuse) {
         hipError_t e = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);
         if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
     }
-    if (!rc) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
+    if (!rc && !reuse) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
     if (!rc) {
         hipError_t e = hipEventRecord(c->ev_join, c->aux_stream);
         if (e != hipSuccess) rc = hipfail(c, e, "hipEventRecord");
@@ -368,7 +397,12 @@ struct Stager {
     sb_ctx *c;
     size_t next = 0;
     int rc = SB_OK;
-    explicit Stager(sb_ctx *ctx) : c(ctx) {}
+    // the staged copy of sigma sits at the same device address whatever the caller passed: the static-sigma
+    // option is honoured by the device-pointer entry points only
+    explicit Stager(sb_ctx *ctx) : c(ctx) { if (c) { ++c->host_depth; c->stats_valid = false; } }
+    ~Stager() { if (c) --c->host_depth; }
+    Stager(const Stager &) = delete;
+    Stager &operator=(const Stager &) = delete;
     template <typename T>
     T *in(const T *host, size_t n) {       // upload
         T *d = out<T>(n);
@@ -774,7 +808,24 @@ int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const
     HIPCHK(c, hipStreamSynchronize(st));   // hv is a local: the copy must land before it dies
     const T *dphi = (const T *)c->vecs.p, *dlam = dphi + ny;
     if ((rc = ensure(c, c->coastbits, (size_t)ny * ((nx + 63) / 64) * sizeof(uint64_t)))) return rc;
-    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, (uint64_t *)c->coastbits.p, st));
+    // k_dist_bits may keep only the nearest hit on each side of a source row when the haversine term grows with
+    // the index distance inside the window: longitudes that step strictly eastwards once round the circle (the
+    // closing step from the last column to the first included) and k steps that stay short of half of it
+    double turn = 0.0, maxstep = 0.0;
+    bool mono = nx > 1;
+    for (int j = 0; j < nx && mono; ++j) {
+        double d = std::fmod((double)lon[(j + 1) % nx] - (double)lon[j], 360.0);
+        if (d < 0) d += 360.0;
+        mono = d > 1.0e-6;
+        turn += d;
+        maxstep = d > maxstep ? d : maxstep;
+    }
+    bool latmono = true;                      // sp^2 grows with the row distance: latitudes step one way
+    for (int i = 0; i + 2 < ny && latmono; ++i)
+        latmono = ((double)lat[i + 1] - (double)lat[i]) * ((double)lat[i + 2] - (double)lat[i + 1]) > 0.0;
+    for (int i = 0; i < ny && latmono; ++i) latmono = std::fabs((double)lat[i]) <= 90.0;
+    const int nearest = (mono && latmono && turn < 360.0 + 1.0e-3 && (double)k * maxstep < 170.0) ? 1 : 0;
+    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, (uint64_t *)c->coastbits.p, nearest, st));
     // a distance field made here bounds the search radius of the following diag calls
     c->radius_hint = k + 1;
     return SB_OK;
@@ -1157,14 +1208,18 @@ int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream)
         if (!south) {
             NCCLCHK(c, g_rccl.Send(field + slab, slab, dt, c->rank - 1, comm, st));
             NCCLCHK(c, g_rccl.Recv(field, slab, dt, c->rank - 1, comm, st));
+            c->rep_rccl += 2;
         }
         if (!north) {
             NCCLCHK(c, g_rccl.Send(field + rowlen * ny, slab, dt, c->rank + 1, comm, st));
             NCCLCHK(c, g_rccl.Recv(field + rowlen * (ny + halo), slab, dt, c->rank + 1, comm, st));
+            c->rep_rccl += 2;
         }
         NCCLCHK(c, g_rccl.GroupEnd());
+        c->rep_groups += 1;
     }
     HIPCHK(c, sb_launch_fill_ghosts<T>(field, nx, ny, halo, south ? 1 : 0, north ? 1 : 0, st));
+    c->rep_launches += 1;
     return SB_OK;
 }
 }  // namespace
@@ -1337,9 +1392,25 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (c->nranks == 1) {
         HIPCHK(c, hipMemcpyAsync(gathered, mine5, 5 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        c->rep_copies += 1;
         return SB_OK;
     }
     NCCLCHK(c, g_rccl.AllGather(mine5, gathered, 5, ncclDouble, (ncclComm_t)c->comm, st));
+    c->rep_rccl += 1;
+    return SB_OK;
+}
+
+int sb_set_static_sigma(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->static_sigma = on ? 1 : 0;
+    c->stats_valid = false;
+    return SB_OK;
+}
+
+int sb_last_step_report(sb_ctx *c, int report[4]) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!report) return fail(c, SB_ERR_ARG, "null pointer");
+    report[0] = c->rep_launches; report[1] = c->rep_rccl; report[2] = c->rep_groups; report[3] = c->rep_copies;
     return SB_OK;
 }
 

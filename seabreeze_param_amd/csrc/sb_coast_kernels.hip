@@ -11,39 +11,66 @@
 #include "sb_launch.hpp"
 
 template <typename T>
-__device__ __forceinline__ int land_rule(const T *lsm, const T *ci, size_t i, int rule) {
-    const T l = lsm[i], c = ci[i];
+__device__ __forceinline__ int land_rule(T l, T c, int rule) {
     if (rule == 0) return (l + c > T(0.4)) ? 1 : 0;            // ref: sobel.f90:51,69
     if (c <= T(0.2)) return (l >= T(0.5)) ? 1 : 0;             // ref: generic :325-330
     return (l + c >= T(0.5)) ? 1 : 0;                          // ref: generic :332-336
 }
 
+// A workgroup classifies the cells of a 256-column x EDGE_ROWS-row block and of the ring round it once
+// (two loads per cell instead of eighteen), keeps the land flags in LDS and takes the nine-point sums
+// from there.  The boundary mapping (cyclic longitudes with the f2py flavour's column quirk, clamped
+// latitudes; ref: sobel.f90:60-66, generic :340-352) is applied to the staged cell, so a flag means
+// exactly what the reference's inner loop would have read at that offset.
+#define EDGE_ROWS 8
+#define EDGE_PITCH 264
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_edges(const T *__restrict__ lsm, const T *__restrict__ ci,
                                                T *__restrict__ coast, Geo g, int rule) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    __shared__ unsigned char s_land[(EDGE_ROWS + 2) * EDGE_PITCH];
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * EDGE_ROWS;
+    constexpr int NCELL = (EDGE_ROWS + 2) * 258, NIT = (NCELL + 255) / 256;
+    T l[NIT], c[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {                      // every load issued before the first is used
+        const int i = threadIdx.x + 256 * j, r = i / 258, cc = i - r * 258;
+        int X, Y;
+        sb_map_cell(g, x0 - 1 + cc, y0 - 1 + (r < EDGE_ROWS + 2 ? r : 0), X, Y);
+        const size_t o = (size_t)Y * g.nx + X;
+        l[j] = lsm[o];
+        c[j] = ci[o];
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = threadIdx.x + 256 * j, r = i / 258, cc = i - r * 258;
+        const int land = land_rule(l[j], c[j], rule);
+        if (i < NCELL) s_land[r * EDGE_PITCH + cc] = (unsigned char)land;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
     if (x >= g.nx) return;
-    int m[3][3];   // [lat offset + 1][lon offset + 1]
-#pragma unroll
-    for (int a = -1; a <= 1; ++a)
-#pragma unroll
-        for (int b = -1; b <= 1; ++b) {
-            int X, Y;
-            sb_map_cell(g, x + b, y + a, X, Y);
-            m[a + 1][b + 1] = land_rule(lsm, ci, (size_t)Y * g.nx + X, rule);
-        }
     // weight = reshape((/-1,-2,-1, 0,0,0, 1,2,1/),(3,3)) column-major: w(r,c) = (1,2,1)(r) * (-1,0,1)(c)
     // px += w(a+2, b+2)*m, py += w(b+2, a+2)*m     ref: sobel.f90:74-75
-    const int w3[3] = {1, 2, 1};
-    int px = 0, py = 0;
+    // -> px = sum_a (1,2,1)(a) * (m[a][2] - m[a][0]),  py = sum_b (1,2,1)(b) * (m[2][b] - m[0][b])
+    int m[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) m[a + 1][b] = s_land[a * EDGE_PITCH + threadIdx.x + b];
+#pragma unroll
+    for (int r = 0; r < EDGE_ROWS; ++r) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            px += w3[a] * (b - 1) * m[a][b];
-            py += w3[b] * (a - 1) * m[a][b];
+            m[0][b] = m[1][b];
+            m[1][b] = m[2][b];
+            m[2][b] = s_land[(r + 2) * EDGE_PITCH + threadIdx.x + b];
         }
-    coast[(size_t)y * g.nx + x] = (px == 0 && py == 0) ? T(0) : T(1);   // sqrt(px^2+py^2) == 0
+        const int px = (m[0][2] - m[0][0]) + 2 * (m[1][2] - m[1][0]) + (m[2][2] - m[2][0]);
+        const int py = (m[2][0] - m[0][0]) + 2 * (m[2][1] - m[0][1]) + (m[2][2] - m[0][2]);
+        const int y = y0 + r;
+        if (y < g.ny) coast[(size_t)y * g.nx + x] = (px == 0 && py == 0) ? T(0) : T(1);   // sqrt(px^2+py^2) == 0
+    }
 }
 
 
@@ -106,8 +133,23 @@ __global__ __launch_bounds__(256) void k_dist(const T *__restrict__ coast, const
 // grid): k_coastbits packs coast > 0 into one 64-bit word per 64-cell longitude segment
 // (a wave ballot); k_dist_bits pulls the (2k+1)-column window of each source row out of at
 // most four words and visits set bits only.  Nine targets in ten have an empty window and
-// cost a few hundred instructions instead of (2k+1)^2 byte probes.  Same arithmetic per
-// coast hit as k_dist, same early/late bookkeeping, same results.
+// cost a few hundred instructions instead of (2k+1)^2 byte probes.
+//
+// Two further cuts, both exact up to the last place of atan2:
+//   * the distance c = 2R atan2(sqrt(a), sqrt(1-a)) + 0.5 (ref: sobel.f90:176-177) grows with a,
+//     so the minimum of c over a class of sources is c at the minimum of a: the kernel keeps
+//     min(a) of the sources swept before and after the target and takes two atan2 per cell
+//     instead of one per coast hit;
+//   * within one source row a = sp^2 + cos(phis) cos(phit) sin^2(dlam/2) grows with the
+//     longitude distance, so of the hits left of (or at) the target column only the nearest can
+//     be the minimum, and likewise on the right: two hits per row instead of up to 2k+1.  On the
+//     target's own row the sweep order splits each side once more where the window crosses the
+//     seam (xs <= xx is decided on wrapped indices, ref: sobel.f90:188), so up to four there.
+//   * a >= sp^2, which grows with the row distance: the walk away from the target row stops early.
+//     `nearest` (both row cuts) is set by the host only when the longitudes step one way round the circle,
+//     the window spans less than half of it and the latitudes step one way (sb_capi.hip); otherwise every
+//     hit of every row is visited.
+// Same arithmetic per visited hit as k_dist, same early/late bookkeeping.
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_coastbits(const T *__restrict__ coast, uint64_t *__restrict__ bits,
@@ -126,33 +168,73 @@ __device__ __forceinline__ uint64_t row_bits(const uint64_t *__restrict__ rw, in
     return v & ((1ull << l) - 1ull);
 }
 
+__device__ __forceinline__ uint64_t top_bit(uint64_t x) { return x ? 1ull << (63 - __builtin_clzll(x)) : 0ull; }
+__device__ __forceinline__ uint64_t low_bit(uint64_t x) { return x & (0ull - x); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_dist_bits(const uint64_t *__restrict__ bits, const T *__restrict__ mask,
                                                    const T *__restrict__ phi, const T *__restrict__ lamf,
                                                    T *__restrict__ cdist, int nx, int ny, int nw, int k,
-                                                   T maxdist) {
+                                                   T maxdist, int nearest) {
+    // the latitude factors of the 2k+1 source rows are the same for every target of this row: once per workgroup
+    __shared__ T s_sp2[64], s_cosp[64];
     const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    const T phit = phi[yy];
+    if ((int)threadIdx.x <= 2 * k) {
+        int ys = yy + (int)threadIdx.x - k;
+        ys = ys < 0 ? 0 : (ys >= ny ? ny - 1 : ys);
+        const T phis = phi[ys];
+        const T dphi = phis - phit;                              // phi1(i) - phi1(yy)
+        const T sp = sin(dphi / T(2));
+        s_sp2[threadIdx.x] = sp * sp;
+        s_cosp[threadIdx.x] = cos(phis);
+    }
+    __syncthreads();
+    // Which of the 2k+1 source rows hold any coast cell within reach of this wave's 64 targets?  Lane i ORs the
+    // (at most three) words of row yy - k + i that cover columns x0 - k .. x0 + 63 + k; the ballot is a row mask in
+    // scalar registers, and rows without a bit are skipped by the whole wave.  Four targets in five see no coast
+    // at all and end here after one load round.  A wave whose reach crosses the seam keeps every row.
+    uint64_t rowmask;
+    {
+        const int lane = threadIdx.x & 63, wx0 = blockIdx.x * 256 + ((int)threadIdx.x & ~63);
+        const bool seam = wx0 - k < 0 || wx0 + 63 + k >= nx;
+        const int ys = yy + lane - k;
+        uint64_t any = 0;
+        if (lane <= 2 * k && ys >= 0 && ys < ny) {
+            if (seam) any = 1;
+            else
+                for (int w = (wx0 - k) >> 6; w <= (wx0 + 63 + k) >> 6; ++w) any |= bits[(size_t)ys * nw + w];
+        }
+        rowmask = __ballot(any != 0);
+    }
     if (xx >= nx) return;
     const T R = T(6370.9989);                                   // ref: sobel.f90:115
     const T big = T(12000.);
-    const T phit = phi[yy], lamt = lamf[xx];
+    const T lamt = lamf[xx];
     const T cost = cos(phit);
     const int L = 2 * k + 1;
     int start = (xx - k) % nx;                                   // first window column, circular
     if (start < 0) start += nx;
     const int len1 = L < nx - start ? L : nx - start;
-    T m_early = big, m_late = big;
-    for (int ii = -k; ii <= k; ++ii) {
+    // window bit b is column xx - k + b: bits 0 .. k lie left of or at the target, the rest right of it;
+    // bits below k - xx and from nx - xx + k on have wrapped round the seam
+    const uint64_t left = (2ull << k) - 1ull;
+    const uint64_t wrapl = (k - xx > 0) ? (1ull << (k - xx)) - 1ull : 0ull;
+    const uint64_t wrapr = (nx - xx + k < 64) ? ~0ull << (nx - xx + k) : 0ull;
+    const T none = T(4);                                         // a <= 1: "no source in this class"
+    T a_early = none, a_late = none;
+    auto row = [&](int ii) {
         const int ys = yy + ii;
-        if (ys < 0 || ys >= ny) continue;                        // clamped rows add no new sources
         const uint64_t *rw = bits + (size_t)ys * nw;
         uint64_t wb = row_bits(rw, start, len1);
         if (len1 < L) wb |= row_bits(rw, 0, L - len1) << len1;
-        if (!wb) continue;
-        const T phis = phi[ys];
-        const T dphi = phis - phit;                              // phi1(i) - phi1(yy)
-        const T sp = sin(dphi / T(2));
-        const T cosp = cos(phis);
+        if (!wb) return;
+        if (nearest) {
+            const uint64_t wl = wb & left, wr = wb & ~left;
+            if (ii != 0) wb = top_bit(wl) | low_bit(wr);
+            else wb = top_bit(wl & ~wrapl) | top_bit(wl & wrapl) | low_bit(wr & ~wrapr) | low_bit(wr & wrapr);
+        }
+        const T sp2 = s_sp2[ii + k], cosp = s_cosp[ii + k];
         while (wb) {
             const int b = __builtin_ctzll(wb);
             wb &= wb - 1;
@@ -160,13 +242,29 @@ __global__ __launch_bounds__(256) void k_dist_bits(const uint64_t *__restrict__ 
             if (xs >= nx) xs -= nx;
             const T dlam = lamf[xs] - lamt;                      // l1 - l2
             const T sl = sin(dlam / T(2));
-            const T a = sp * sp + (cosp * (cost * (sl * sl)));   // ref: sobel.f90:176
-            const T c = (R * T(2)) * atan2(sqrt(a), sqrt(T(1) - a)) + T(0.5);   // ref :177
+            const T a = sp2 + (cosp * (cost * (sl * sl)));       // ref: sobel.f90:176
             const bool early = (ys < yy) || (ys == yy && xs <= xx);
-            if (early) m_early = c < m_early ? c : m_early;
-            else m_late = c < m_late ? c : m_late;
+            if (early) a_early = a < a_early ? a : a_early;
+            else a_late = a < a_late ? a : a_late;
         }
+    };
+    // Rows above the target are swept before it, rows below after it.  a >= sp2 of its row, and with latitudes
+    // that step one way (the host's condition for `nearest`) sp2 grows with the row distance: a walk away
+    // from the target can stop at the first row whose sp2 is no smaller than the class's minimum so far.
+    if ((rowmask >> k) & 1) row(0);
+    for (int d = 1; d <= k && yy - d >= 0; ++d) {                // clamped rows add no new sources
+        if (!((rowmask >> (k - d)) & 1)) continue;               // wave-uniform
+        if (nearest && !(s_sp2[k - d] < a_early)) break;
+        row(-d);
     }
+    for (int d = 1; d <= k && yy + d < ny; ++d) {
+        if (!((rowmask >> (k + d)) & 1)) continue;
+        if (nearest && !(s_sp2[k + d] < a_late)) break;
+        row(d);
+    }
+    T m_early = big, m_late = big;
+    if (a_early < none) m_early = (R * T(2)) * atan2(sqrt(a_early), sqrt(T(1) - a_early)) + T(0.5);   // ref :177
+    if (a_late < none) m_late = (R * T(2)) * atan2(sqrt(a_late), sqrt(T(1) - a_late)) + T(0.5);
     if (m_early > T(2) * maxdist) m_early = big;                 // ref: sobel.f90:188 at sweep time
     const T m = m_early < m_late ? m_early : m_late;
     const size_t o = (size_t)yy * nx + xx;
@@ -178,18 +276,18 @@ template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st) {
     Geo g;
     g.nx = nx; g.ny = ny; g.h = 0; g.nxh = nx; g.nyh = ny; g.nw = (nx + 63) / 64; g.bnd = bnd; g.rows = ny;
-    hipLaunchKernelGGL(k_edges<T>, dim3((nx + 255) / 256, ny), dim3(256), 0, st, lsm, ci, coast, g, rule);
+    hipLaunchKernelGGL(k_edges<T>, dim3((nx + 255) / 256, (ny + EDGE_ROWS - 1) / EDGE_ROWS), dim3(256), 0, st, lsm, ci, coast, g, rule);
     return hipGetLastError();
 }
 
 template <typename T>
 hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
-                          int k, T maxdist, uint64_t *bits, hipStream_t st) {
+                          int k, T maxdist, uint64_t *bits, int nearest, hipStream_t st) {
     if (bits && k <= 31 && 2 * k + 1 <= nx) {
         const int nw = (nx + 63) / 64;
         hipLaunchKernelGGL(k_coastbits<T>, dim3((nx + 255) / 256, ny), dim3(256), 0, st, coast, bits, nx, ny, nw);
         hipLaunchKernelGGL(k_dist_bits<T>, dim3((nx + 255) / 256, ny), dim3(256), 0, st, bits, mask, phi, lamf, cdist,
-                           nx, ny, nw, k, maxdist);
+                           nx, ny, nw, k, maxdist, nearest);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(64 + 2 * k) * (SB_DIST_TY + 2 * k);
@@ -202,6 +300,6 @@ hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *
 template hipError_t sb_launch_edges<float>(const float *, const float *, float *, int, int, int, int, hipStream_t);
 template hipError_t sb_launch_edges<double>(const double *, const double *, double *, int, int, int, int, hipStream_t);
 template hipError_t sb_launch_dist<float>(const float *, const float *, const float *, const float *, float *, int,
-                                          int, int, float, uint64_t *, hipStream_t);
+                                          int, int, float, uint64_t *, int, hipStream_t);
 template hipError_t sb_launch_dist<double>(const double *, const double *, const double *, const double *, double *,
-                                           int, int, int, double, uint64_t *, hipStream_t);
+                                           int, int, int, double, uint64_t *, int, hipStream_t);

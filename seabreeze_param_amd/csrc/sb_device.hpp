@@ -162,7 +162,7 @@ struct SbSegEntry {
     uint64_t word;
     uint32_t seg, pad;
 };
-#define SB_SEG_PARTS 16              // k_prep workgroups that compact the segment list, one sub-list each
+#define SB_SEG_PARTS 64              // k_prep workgroups that compact the segment list, one sub-list each
 
 template <typename T>
 struct DiagJob {

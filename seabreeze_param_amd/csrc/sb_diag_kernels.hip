@@ -7,7 +7,7 @@
 //   k_scan   one pass over sigma and mask: per-workgroup moments of sigma, the band and
 //            land-side bit planes, tile flags, and the fill value for every cell outside
 //            the coastal band                                                  [HBM stream]
-//   k_prep   18 workgroups: the moments merged into the sigmoid scalars, the tile flags
+//   k_prep   2 + SB_SEG_PARTS workgroups: the moments merged into the sigmoid scalars, the tile flags
 //            compacted into the list of active tiles (for k_thc3), the band plane into the
 //            list of 64-cell segments that hold band cells (for k_wind)        [tiny]
 //   k_t0     f2py flavour only: the t0 plane is an output there               [HBM stream]
@@ -306,7 +306,7 @@ template hipError_t sb_launch_theta_to_t0<double>(double *, const double *, cons
 
 // ------------------------------------------------------------------------------------
 // k_prep: the small jobs between k_scan and the kernels that consume its flags, one role per
-// workgroup (18 workgroups, ~2 us), so that neither the 256 persistent workgroups of k_thc3 nor
+// workgroup (2 + SB_SEG_PARTS workgroups), so that neither the 256 persistent workgroups of k_thc3 nor
 // the waves of k_wind repeat them:
 //   block 0               k_scan's per-workgroup moments merged, in the fixed order and tree of
 //                         k_moments_final, into the sigmoid scalars (or published as this band's
@@ -559,7 +559,9 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     hipEvent_t *ev = lc.prof;
     const bool gathered = lc.gathered != nullptr;
     const bool ph1 = (lc.phases & 1) != 0, ph2 = (lc.phases & 2) != 0;
+    const bool reuse = lc.reuse_stats;
     hipError_t e = hipSuccess;
+    int nl = 0;                                                  // kernels enqueued
     const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
     int nblk = (int)((nseg + 79) / 80);                          // 16 waves x 5 segments per trip
     if (nblk < 1) nblk = 1;
@@ -570,15 +572,17 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     // applies them.
     if (job.wind_final && ph1 && ph2) {
         SB_EV_BEGIN(SB_PROF_SCAN);
-        launch_scan<T>(job, nblk, lc.partials, true, st);
+        launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
         SB_EV_BEGIN(SB_PROF_PREP);
-        hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, nblk, (T *)lc.stats, (Moments *)nullptr);
+        hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, reuse ? 0 : nblk, (T *)lc.stats, (Moments *)nullptr);
         SB_EV_END(SB_PROF_PREP);
+        nl += 2;
         if (!job.t0_fly) {
             SB_EV_BEGIN(SB_PROF_T0);
             hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
             SB_EV_END(SB_PROF_T0);
+            ++nl;
         }
         SB_EV_BEGIN(SB_PROF_THC);
         if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
@@ -586,13 +590,15 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         SB_EV_BEGIN(SB_PROF_WIND);
         launch_wind<T>(job, lc.ncu, st);
         SB_EV_END(SB_PROF_WIND);
+        nl += 2;
+        if (lc.launches) *lc.launches += nl;
         return hipGetLastError();
     }
     // ---- phase 1: needs neither theta's ghost cells nor the statistics of the other bands ---------
     if (ph1) {
         // a band step takes this band's own sigma moments from the same pass (lc.moments_out), publishes
         // them for the all-gather and signals the communication stream
-        const bool own_stats = !gathered || lc.moments_out != nullptr;
+        const bool own_stats = (!gathered || lc.moments_out != nullptr) && !reuse;
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, own_stats, st);
         SB_EV_END(SB_PROF_SCAN);
@@ -600,24 +606,31 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats ? nblk : 0, (T *)lc.stats,
                            gathered ? lc.moments_out : (Moments *)nullptr);
         SB_EV_END(SB_PROF_PREP);
-        if (gathered && lc.moments_out && lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
+        if (own_stats && gathered && lc.moments_out && lc.moments_event &&
+            (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
         SB_EV_BEGIN(SB_PROF_WIND);
         launch_wind<T>(job, lc.ncu, st);
         SB_EV_END(SB_PROF_WIND);
+        nl += 3;
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
-        if (gathered)
+        if (gathered && !reuse) {
             hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered, (T *)lc.stats);
+            ++nl;
+        }
         if (!job.t0_fly) {
             SB_EV_BEGIN(SB_PROF_T0);
             hipLaunchKernelGGL(k_t0<T>, dim3((g.nxh + 255) / 256, g.nyh), dim3(256), 0, st, job);
             SB_EV_END(SB_PROF_T0);
+            ++nl;
         }
         SB_EV_BEGIN(SB_PROF_THC);
         if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
+        ++nl;
     }
+    if (lc.launches) *lc.launches += nl;
     return hipGetLastError();
 }
 

@@ -32,6 +32,8 @@ struct SbLaunchCtx {
     int thc_nt;                     // threads of a k_thc3 workgroup: 512 or 1024
     int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
+    bool reuse_stats;               // the sigmoid scalars in `stats` stand (static sigma): no moments, no merge
+    int *launches;                  // += kernels enqueued by the call, or nullptr
 };
 
 template <typename T>
@@ -57,6 +59,7 @@ hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, 
 template <typename T>
 hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
                           int k, T maxdist, uint64_t *bits,   // bits: ny*ceil(nx/64) words of workspace, or nullptr
+                          int nearest,                        // 1: nearest hit per side of a source row only (see k_dist_bits)
                           hipStream_t st);
 
 // local part of swap_bounds: E-W periodic ghost columns, pole-side ghost rows replicate the edge row

@@ -490,12 +490,13 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         lds_barrier();
         SB_T(5);                               // barrier 2
         // ---- A3: smallest radius whose square holds both classes, contrast, result -----------------------
-        // Two rounds of independent probes instead of a bisection: every probe of a round is issued before
-        // the first is used, so a cell costs three LDS round trips (two for the radius, one for the sums).
-        // QI list entries of a thread go through the rounds together (all of them while a SIMD holds only two
-        // waves; one at a time at four waves per SIMD, where the other waves cover the round trips and the
-        // register budget is half).  Without ghost-cell limits (every boundary rule but SB_BND_HALO) the radii of
-        // a round are constants, and so are the table offsets of its sixteen / 4 (STEP - 1) reads.
+        // THC_SEARCH 1 (default): the widest square, then a branch-free bisection on the count table -- 4 u16 reads per
+        // probe, 1 + log2(H) dependent probes; QI list entries of a thread go through the probes together, so their
+        // LDS round trips overlap (all of them while a SIMD holds only two waves; one at a time at four waves per
+        // SIMD, where the other waves cover the round trips and the register budget is half).
+        // THC_SEARCH 0 (kept for measurement): two rounds of independent probes at radii STEP, 2 STEP .. H and then
+        // the STEP - 1 radii below the bracket: 3 round trips instead of 6, but 28 reads instead of 20 -- measured
+        // slower (7.4k against 5.4k cycles per tile): this phase is bound by LDS issue, not by latency.
         {
             constexpr int QI = THC_QI > 0 ? (THC_QI < CPT ? THC_QI : CPT) : (NT >= 1024 ? 1 : CPT);
             int nnmax = 0;

@@ -105,6 +105,16 @@ class Context:
         """512 or 1024 threads per contrast-kernel workgroup (tuning / test knob)."""
         self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
 
+    def set_static_sigma(self, on: bool):
+        """Opt-in: sigma does not change between calls; its statistics are formed once (include/seabreeze_hip.h)."""
+        self._chk(self.lib.sb_set_static_sigma(self.h, C.c_int(1 if on else 0)), "sb_set_static_sigma")
+
+    def last_step_report(self):
+        """What the last diag call / band step enqueued on this rank."""
+        arr = (C.c_int * 4)()
+        self._chk(self.lib.sb_last_step_report(self.h, arr), "sb_last_step_report")
+        return dict(kernel_launches=arr[0], rccl_ops=arr[1], rccl_groups=arr[2], d2d_copies=arr[3])
+
     def last_counters(self):
         arr = (C.c_longlong * 4)()
         self._chk(self.lib.sb_last_counters(self.h, arr), "sb_last_counters")

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nx, ny, nz, tmpdir):
+def _worker(rank, world, port, nx, ny, nz, tmpdir, static_sigma=False):
     sys.path.insert(0, ROOT)
     from oracle.pyoracle import Oracle
     from seabreeze_param_amd import hip, synth
@@ -41,7 +41,7 @@ def _worker(rank, world, port, nx, ny, nz, tmpdir):
         cdist[np.abs(cdist) > 180.0] = 12000.0
         p = synth.pressure_3d(st, nz)
         ctx = hip.Context(0)
-        runner = BandRunner(ctx, torch, dist, rank, world, nx, ny, nz, halo=kwin + 1)
+        runner = BandRunner(ctx, torch, dist, rank, world, nx, ny, nz, halo=kwin + 1, static_sigma=static_sigma)
         runner.upload_static(st.z, st.sigma, cdist)
         full = [np.zeros((ny, nx)) for _ in range(4)]
         r0, r1 = split_rows(ny, world)[rank]
@@ -63,8 +63,9 @@ def _worker(rank, world, port, nx, ny, nz, tmpdir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("static_sigma", [False, True], ids=["default", "static-sigma"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_band_runner_on_one_gpu(tmp_path, world):
+def test_band_runner_on_one_gpu(tmp_path, world, static_sigma):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 160, 96, 4, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 160, 96, 4, str(tmp_path), static_sigma), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

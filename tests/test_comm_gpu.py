@@ -49,8 +49,9 @@ def test_swap_bounds_single_rank(dtype, with_comm):
         ctx.close()
 
 
+@pytest.mark.parametrize("static_sigma", [False, True], ids=["default", "static-sigma"])
 @pytest.mark.parametrize("with_comm", [False, True])
-def test_band_step_single_rank_equals_global(oracles, with_comm):
+def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
     """sb_band_seabreeze_diag_*_dev with one band owning the globe: the ghost frame it fills itself
     (poles replicate, longitude wraps) must give the single-domain SB_BND_GLOBAL result, and the
     fork/join with the communication stream must order correctly over several steps."""
@@ -67,7 +68,9 @@ def test_band_step_single_rank_equals_global(oracles, with_comm):
         if with_comm:
             ctx.comm_init(hip.comm_unique_id(), 0, 1)
         ctx.set_search_radius_hint(h)
+        ctx.set_static_sigma(static_sigma)
         stream = torch.cuda.current_stream().cuda_stream
+        reports = []
 
         def frame(a):
             f = torch.zeros((ny + 2 * h, nx + 2 * h), dtype=torch.float64, device="cuda")
@@ -88,10 +91,63 @@ def test_band_step_single_rank_equals_global(oracles, with_comm):
                                         thf.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
                                         *[s.data_ptr() for s in state], stream)
             torch.cuda.synchronize()
+            reports.append(ctx.last_step_report())
             orc.seabreeze_diag(5400.0, tn, p, u, v, th, cdist, st.z, st.sigma, *ref, halo=0, bnd=1)
             for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
+        # what a band step enqueues (one rank: the all-gather is a 40-byte copy, no neighbours to send to):
+        # ghost fill, k_scan, k_prep, k_wind, moments merge, k_thc3; with static sigma the merge and the copy go
+        assert reports[0] == dict(kernel_launches=6, rccl_ops=0, rccl_groups=0, d2d_copies=1)
+        later = dict(kernel_launches=5, rccl_ops=0, rccl_groups=0, d2d_copies=0) if static_sigma else reports[0]
+        assert all(r == later for r in reports[1:]), reports
+    finally:
+        ctx.close()
+
+
+def test_static_sigma_single_domain(oracles):
+    """sb_set_static_sigma on a single domain: the statistics of the first call stand while the same device
+    array comes back, another array forms them anew, and results equal the default path's bit for bit."""
+    from seabreeze_param_amd import synth
+    nx, ny, nz = 256, 192, 3
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=5)
+    p = synth.pressure_3d(st, nz, dt)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ctx = hip.Context(0)
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        z, mk, pd = dev(st.z), dev(cdist), dev(p)
+        sg_a, sg_b = dev(st.sigma), dev(st.sigma * 1.7 + 3.0)
+        runs = {}
+        for static in (False, True):
+            ctx.set_static_sigma(static)
+            state = [torch.zeros((ny, nx), dtype=torch.float64, device="cuda") for _ in range(4)]
+            outs = []
+            for tn, sg in ((1, sg_a), (2, sg_a), (3, sg_b), (4, sg_b), (5, sg_a)):
+                th = synth.theta_step(st, tn, dt)
+                u, v = synth.wind_step(st, nz, tn, dt)
+                ud, vd, thd = dev(u), dev(v), dev(th)
+                ctx.seabreeze_diag_dev(dt, 7200.0, tn, nx, ny, nz, 0, hip.SB_BND_GLOBAL, pd.data_ptr(), ud.data_ptr(),
+                                       vd.data_ptr(), thd.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
+                                       *[s.data_ptr() for s in state], stream)
+                torch.cuda.synchronize()
+                assert ctx.last_step_report()["kernel_launches"] == 4          # k_scan, k_prep, k_thc3, k_wind
+                outs.append([s.cpu().numpy().copy() for s in state])
+            runs[static] = outs
+        for a, b in zip(runs[False], runs[True]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y, equal_nan=True)
+        # and the default path is the oracle's
+        ref = [np.zeros((ny, nx)) for _ in range(4)]
+        for i, (tn, sg) in enumerate(((1, st.sigma), (2, st.sigma), (3, st.sigma * 1.7 + 3.0))):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, sg, *ref, halo=0, bnd=1)
+            for x, y in zip(runs[True][i], ref):
+                assert np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-2)) < 1e-7
     finally:
         ctx.close()
 

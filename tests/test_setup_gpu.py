@@ -1,0 +1,110 @@
+"""Setup kernels (get_edges, get_dist) against the CPU oracle on inputs chosen to reach every branch of them:
+coast cells on both sides of the longitude seam, every window width class, longitudes for which the nearest-hit
+shortcut of k_dist_bits must be switched off (regional grids, unordered longitudes), the LDS kernel for windows
+wider than 63 columns, and grid sizes that leave ragged blocks in k_edges.
+
+Tolerance: the coast mask is bit-exact; distances to 1e-12 relative (k_dist_bits takes the distance at the smallest
+haversine term instead of the smallest of the distances: the same number unless atan2 is not monotonic in its last
+place), signs exact.
+"""
+import numpy as np
+import pytest
+
+from seabreeze_param_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise_mask(nx, ny, seed, dt, frac=False):
+    """Land mask with coast cells everywhere (blobs of a few cells), also across the seam and at the poles."""
+    r = synth.hash_uniform((ny, nx), 3, seed)
+    s = r + np.roll(r, 1, 1) + np.roll(r, 1, 0) + np.roll(r, -1, 1)
+    land = (s > 2.2).astype(np.float64)
+    if frac:
+        land = np.round(np.clip((s - 1.6) / 1.2, 0, 1) * 8) / 8
+    ice = np.where(synth.hash_uniform((ny, nx), 4, seed) > 0.9, 0.35, 0.0)
+    return np.ascontiguousarray(land, dt), np.ascontiguousarray(ice, dt)
+
+
+def _sparse_mask(nx, ny, seed, dt):
+    """A few isolated islands: most windows empty, some with a single hit far from the target."""
+    r = synth.hash_uniform((ny, nx), 5, seed)
+    land = (r > 0.995).astype(np.float64)
+    land[:, 0] = (r[:, 0] > 0.9)            # islands on the seam column
+    land[:, -1] = (r[:, -1] > 0.93)
+    return np.ascontiguousarray(land, dt), np.zeros((ny, nx), dt)
+
+
+def _check_dist(h, o, what, rel):
+    assert np.array_equal(h >= 12000.0, o >= 12000.0), f"{what}: cells without a coast in reach differ"
+    assert np.array_equal(np.sign(h), np.sign(o)), f"{what}: signs differ"
+    e = np.abs(h - o) / np.maximum(np.abs(o), 1.0)
+    assert e.max() <= rel, f"{what}: max rel err {e.max()}"
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("shape,kwin", [((200, 90), 1), ((200, 90), 5), ((130, 64), 15), ((130, 40), 31), ((64, 33), 31),
+                                        ((70, 30), 20)])
+def test_get_dist_global_seam(hipctx, oracles, shape, kwin, prec):
+    nx, ny = shape
+    dt, orc = (np.float64, oracles[8]) if prec == 8 else (np.float32, oracles[4])
+    lon, lat = synth.grid(nx, ny)
+    for maker, seed in ((_noise_mask, 11), (_sparse_mask, 12)):
+        land, ice = maker(nx, ny, seed, dt)
+        coast = orc.get_edges(land, ice)
+        assert np.array_equal(hipctx.get_edges(land, ice), coast)
+        for maxdist in (180.0, 900.0):       # the sweep-time reset (sobel.f90:188) at two thresholds
+            o = orc.get_dist(coast, land, lon.astype(dt), lat.astype(dt), maxdist=maxdist, kwin=kwin)
+            h = hipctx.get_dist(coast, land, lon.astype(dt), lat.astype(dt), maxdist=maxdist, kwin=kwin)
+            _check_dist(h, o, f"{maker.__name__} {shape} k={kwin} maxdist={maxdist}", 1e-12 if prec == 8 else 2e-6)
+
+
+@pytest.mark.parametrize("lons", ["regional", "shuffled", "descending", "repeated", "lat-shuffled", "lat-descending"])
+def test_get_dist_every_hit_path(hipctx, oracles, lons):
+    """Coordinates for which the haversine term need not grow with the index distance inside a row, or with the row
+    distance: the host must leave the shortcuts of k_dist_bits off (or, for descending latitudes, may leave them
+    on), and the kernel must still give the reference's minimum."""
+    nx, ny, kwin = 150, 60, 9
+    dt, orc = np.float64, oracles[8]
+    _, lat = synth.grid(nx, ny)
+    lon = {"regional": np.linspace(100.0, 160.0, nx),                       # closing step of 300 degrees
+           "shuffled": np.random.default_rng(5).permutation(np.linspace(0.0, 357.6, nx)),
+           "descending": np.linspace(357.6, 0.0, nx),
+           "repeated": np.repeat(np.linspace(0.0, 355.2, nx // 2), 2)}.get(lons, synth.grid(nx, ny)[0])
+    if lons == "lat-shuffled":
+        lat = np.random.default_rng(6).permutation(lat)
+    if lons == "lat-descending":
+        lat = lat[::-1].copy()
+    land, ice = _noise_mask(nx, ny, 21, dt)
+    coast = orc.get_edges(land, ice)
+    o = orc.get_dist(coast, land, lon, lat, maxdist=400.0, kwin=kwin)
+    h = hipctx.get_dist(coast, land, lon, lat, maxdist=400.0, kwin=kwin)
+    _check_dist(h, o, lons, 1e-12)
+
+
+@pytest.mark.parametrize("kwin", [32, 40])
+def test_get_dist_wide_window_lds_kernel(hipctx, oracles, kwin):
+    """Windows wider than 63 columns do not fit the bit-plane kernel: k_dist (flags in LDS) takes over."""
+    nx, ny = 192, 48
+    dt, orc = np.float64, oracles[8]
+    lon, lat = synth.grid(nx, ny)
+    land, ice = _sparse_mask(nx, ny, 31, dt)
+    coast = orc.get_edges(land, ice)
+    o = orc.get_dist(coast, land, lon, lat, maxdist=5000.0, kwin=kwin)
+    h = hipctx.get_dist(coast, land, lon, lat, maxdist=5000.0, kwin=kwin)
+    _check_dist(h, o, f"k={kwin}", 1e-12)
+
+
+@pytest.mark.parametrize("prec", [8, 4])
+@pytest.mark.parametrize("shape", [(258, 7), (513, 9), (256, 8), (255, 17), (64, 3), (5, 5), (1030, 25)])
+def test_get_edges_ragged_blocks(hipctx, oracles, shape, prec):
+    """k_edges works on 256 x 8 blocks with a ring staged in LDS: sizes that leave partial blocks in both
+    directions, both land rules and both boundary treatments, fractional land and ice."""
+    nx, ny = shape
+    dt, orc = (np.float64, oracles[8]) if prec == 8 else (np.float32, oracles[4])
+    land, ice = _noise_mask(nx, ny, 41, dt, frac=True)
+    for rule, bnd_o, bnd_h in ((0, 0, hip.SB_BND_WRAPPER), (1, 1, hip.SB_BND_GLOBAL), (0, 1, hip.SB_BND_GLOBAL),
+                               (1, 0, hip.SB_BND_WRAPPER)):
+        o = orc.get_edges(land, ice, rule=rule, bnd=bnd_o)
+        h = hipctx.get_edges(land, ice, rule=rule, bnd=bnd_h)
+        assert np.array_equal(h, o), f"{shape} rule={rule} bnd={bnd_o}: {np.count_nonzero(h != o)} cells differ"
