@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     ap.add_argument("--thc-threads", type=int, default=0, help="tuning: 512 or 1024 threads per k_thc3 workgroup")
+    ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
+    ap.add_argument("--static-sigma", action="store_true",
+                    help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
     args = ap.parse_args()
 
     import torch
@@ -229,6 +232,8 @@ def main():
     ctx = hip.Context(local_rank)
     if args.thc_threads:
         ctx.set_thc_threads(args.thc_threads)
+    if args.no_fold:
+        ctx.set_fold(False)
     if world > 1 and comm == "native":
         # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
         uid = [hip.comm_unique_id() if rank == 0 else None]
@@ -264,7 +269,7 @@ def main():
     gen_s = time.perf_counter() - t_gen
 
     runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1, dtype=dt,
-                        comm=comm if world > 1 else "torch", rows=rows)
+                        comm=comm if world > 1 else "torch", rows=rows, static_sigma=args.static_sigma)
     runner.upload_static(st.z, st.sigma, cdist)
     # two input sets at different addresses: B swaps u and v (distinct synthetic winds) and
     # uses the next step's theta, so no step re-reads the lines the previous one fetched
@@ -360,6 +365,8 @@ def main():
             "band_fraction": n_band_total / (nx * ny),
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
+            "variant": ("static-sigma (opt-in; not the reference's per-call statistics)" if args.static_sigma else "default")
+                       + (", k_prep as its own kernel" if args.no_fold else ""),
             "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
             "multi_rank_rccl": "unmeasured on hardware so far (one GPU per box in the build pool)" if world == 1 else "this run",
             "input_gen_s": round(gen_s, 1),

@@ -90,6 +90,10 @@ int  sb_set_tile_rows(sb_ctx *ctx, int rows);
 /* Threads of the contrast kernel's workgroups for halos up to 16: 512 (8 waves of up to 256 registers, the
    default) or 1024 (16 waves of up to 128).  A tuning and test knob: results never depend on it.       */
 int  sb_set_thc_threads(sb_ctx *ctx, int threads);
+/* Single-domain host-model calls let the contrast kernel merge k_scan's statistics, pick its tiles and compact
+   k_wind's segment lists itself (on, the default) or leave that to a kernel of its own between k_scan and
+   the contrast kernel (off).  A measurement and test knob: results never depend on it.                  */
+int  sb_set_fold(sb_ctx *ctx, int on);
 /* Opt-in, off by default: the caller states that sigma (the sub-grid orography deviation, an ancillary that a
    host model reads once; ref: generic/sea_breeze_diag.f90:159-166 recomputes its mean and deviation every
    call) does not change between calls.  The first complete diag / band step after the switch forms the

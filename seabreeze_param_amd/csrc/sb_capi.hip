@@ -57,6 +57,7 @@ struct sb_ctx {
     int static_sigma = 0;
     bool stats_valid = false;
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
+    int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
     // what the last diag / band step enqueued (sb_last_step_report)
@@ -232,6 +233,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.moments_event = (phases & 1) ? c->band_moments_event : nullptr;
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
+    lc.no_fold = c->no_fold != 0;
+    job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     int launched = 0;
     lc.launches = &launched;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
@@ -1397,6 +1400,12 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
     }
     NCCLCHK(c, g_rccl.AllGather(mine5, gathered, 5, ncclDouble, (ncclComm_t)c->comm, st));
     c->rep_rccl += 1;
+    return SB_OK;
+}
+
+int sb_set_fold(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->no_fold = on ? 0 : 1;
     return SB_OK;
 }
 

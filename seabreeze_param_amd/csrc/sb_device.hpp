@@ -80,6 +80,66 @@ __device__ __forceinline__ double sb_readlane_f64(double v, int l) {
 
 #define SB_STATS_NT 1024             // threads of every workgroup that merges moments
 
+// k_scan's partial results are SHIFTED SUMS about a shift c common to the whole call (the first interior value of
+// sigma): count, sum (x - c), sum (x - c)^2, min, max -- kept in a Moments (n, mean <- s1, m2 <- s2, mn, mx).
+// Merging them is addition, where merging (n, mean, M2) triples costs a division per pair: the merge sits on
+// the critical path of every k_thc3 workgroup (or of k_prep).  One conversion at the end (moments_from_shifted).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sb_dpp_f64_self(double v) {    // lanes without a source keep their own value
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sb_wave_scan_min_f64(double v) {
+    v = fmin(v, sb_dpp_f64_self<0x111, 0xf>(v));
+    v = fmin(v, sb_dpp_f64_self<0x112, 0xf>(v));
+    v = fmin(v, sb_dpp_f64_self<0x114, 0xf>(v));
+    v = fmin(v, sb_dpp_f64_self<0x118, 0xf>(v));
+    v = fmin(v, sb_dpp_f64_self<0x142, 0xa>(v));
+    v = fmin(v, sb_dpp_f64_self<0x143, 0xc>(v));
+    return v;
+}
+// totals of the NW waves' shifted sums, in every thread: wave totals to LDS, one barrier (the caller's, if it has other
+// business with it), then the wave totals added in wave order -- so that workgroups of different sizes agree bit for
+// bit as long as the waves beyond the data hold the empty set
+__device__ __forceinline__ void wave_total_shifted_store(Moments v, Moments *wpart) {
+    v.n = sb_wave_scan_add_f64(v.n);
+    v.mean = sb_wave_scan_add_f64(v.mean);
+    v.m2 = sb_wave_scan_add_f64(v.m2);
+    v.mn = sb_wave_scan_min_f64(v.mn);
+    v.mx = -sb_wave_scan_min_f64(-v.mx);
+    if ((threadIdx.x & 63) == 63) wpart[threadIdx.x >> 6] = v;
+}
+template <int NW>
+__device__ __forceinline__ Moments block_total_shifted_finish(const Moments *wpart) {
+    Moments r = wpart[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        const Moments o = wpart[w];
+        r.n += o.n; r.mean += o.mean; r.m2 += o.m2;
+        r.mn = fmin(r.mn, o.mn); r.mx = fmax(r.mx, o.mx);
+    }
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ Moments block_total_shifted(Moments v, Moments *wpart) {
+    wave_total_shifted_store(v, wpart);
+    __syncthreads();
+    return block_total_shifted_finish<NW>(wpart);
+}
+// shifted sums -> (n, mean, M2, min, max)
+__host__ __device__ inline Moments moments_of_shifted(double c, const Moments &t) {
+    Moments acc = t;
+    if (t.n > 0.0) {
+        acc.mean = c + t.mean / t.n;
+        acc.m2 = t.m2 - t.mean * t.mean / t.n;
+    } else {
+        acc.mean = 0.0; acc.m2 = 0.0;
+    }
+    return acc;
+}
+
 __device__ __forceinline__ Moments wave_merge(Moments m) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -94,8 +154,10 @@ __device__ __forceinline__ Moments wave_merge(Moments m) {
     return m;
 }
 
-// merge across the waves of a 1024-thread workgroup; the result is valid in thread 0
-__device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
+// merge across the NW waves of a workgroup; the result is valid in thread 0.  The tree is the same for every NW
+// as long as the waves beyond the data hold empty moments (merging an empty set is the identity, bit for bit).
+template <int NW>
+__device__ __forceinline__ Moments block_merge_w(Moments m, Moments *wpart) {
     m = wave_merge(m);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __syncthreads();                             // wpart may still be read from a previous use
@@ -103,10 +165,14 @@ __device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
     __syncthreads();
     Moments r = moments_empty();
     if (threadIdx.x < SB_WAVE) {
-        if (threadIdx.x < SB_STATS_NT / SB_WAVE) r = wpart[threadIdx.x];
+        if (threadIdx.x < NW) r = wpart[threadIdx.x];
         r = wave_merge(r);
     }
     return r;
+}
+// ... of a 1024-thread workgroup
+__device__ __forceinline__ Moments block_merge(Moments m, Moments *wpart) {
+    return block_merge_w<SB_STATS_NT / SB_WAVE>(m, wpart);
 }
 
 // std = 2/sqrt(var/N), r = (max-min)/4 in the working precision
@@ -203,6 +269,12 @@ struct DiagJob {
     SbSegEntry *seg_list;           // SB_SEG_PARTS sub-lists of seg_cap entries: the segments that hold band cells
     int *seg_count;                 // entries in each sub-list
     int seg_cap;
+    // single-domain host-model calls fold k_prep's work into k_thc3 (job.fold): k_scan's partial moments are merged
+    // and the active tiles picked by every workgroup for itself, the segment lists compacted in its last workgroups
+    int fold;
+    const Moments *fold_partials;   // k_scan's per-workgroup moments (fold_nparts of them; 0: the scalars in stats stand)
+    int fold_nparts;
+    T *stats_out;                   // where workgroup 0 publishes the sigmoid scalars
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
     long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock sums per k_thc3 workgroup
 };

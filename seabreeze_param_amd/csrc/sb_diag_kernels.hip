@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
 // k_scan: one persistent 1024-thread workgroup per CU streams sigma and mask.  A wave
 // owns aligned 64-cell longitude segments (four per trip, eight loads in flight), so its
 // ballots are exactly the words of the bit planes.
-//   * sigma  -> shifted sums -> one (n, mean, M2, min, max) partial per workgroup
+//   * sigma  -> shifted sums about its first interior value -> one (count, s1, s2, min, max) partial per workgroup
 //   * mask   -> land-side bit  mask >= 0              ref: generic/sea_breeze_diag.f90:182,200
 //            -> band bit  !(|mask| > maxdist)         ref :174
 //            -> flag of the k_thc tile(s) the segment's band cells fall in
@@ -261,8 +261,12 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
         s0 += step;
     }
     if (!do_stats) return;
+    // the workgroup's shifted sums (sb_device.hpp: merged by addition downstream, converted once at the end)
     __shared__ Moments wpart[STATS_NT / SB_WAVE];
-    store_partial(moments_from_shifted(c, s1, s2, mn, mx, cnt), wpart, partials);
+    Moments t;
+    t.n = (double)cnt; t.mean = s1; t.m2 = s2; t.mn = mn; t.mx = mx;
+    t = block_total_shifted<STATS_NT / SB_WAVE>(t, wpart);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
 // ------------------------------------------------------------------------------------
@@ -308,7 +312,7 @@ template hipError_t sb_launch_theta_to_t0<double>(double *, const double *, cons
 // k_prep: the small jobs between k_scan and the kernels that consume its flags, one role per
 // workgroup (2 + SB_SEG_PARTS workgroups), so that neither the 256 persistent workgroups of k_thc3 nor
 // the waves of k_wind repeat them:
-//   block 0               k_scan's per-workgroup moments merged, in the fixed order and tree of
+//   block 0               k_scan's per-workgroup shifted sums added up in index order, in the fixed tree of
 //                         k_moments_final, into the sigmoid scalars (or published as this band's
 //                         moments for the multi-GPU gather)
 //   block 1               tile flags -> row-major list of active tiles: tile_list[0] = count, then the tiles, then
@@ -339,9 +343,15 @@ __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
         if (nparts <= 0) return;
-        Moments m = moments_empty();
-        for (int b = tid; b < nparts; b += PREP_NT) m = moments_merge(m, partials[b]);
-        m = block_merge(m, wpart);
+        // k_scan's shifted sums (about sigma's first interior value) added up in index order, converted once
+        const double c = (double)job.sigma[(size_t)job.g.h * job.g.nxh + job.g.h];
+        Moments v = moments_empty();
+        for (int b = tid; b < nparts; b += PREP_NT) {
+            const Moments o = partials[b];
+            v.n += o.n; v.mean += o.mean; v.m2 += o.m2;
+            v.mn = fmin(v.mn, o.mn); v.mx = fmax(v.mx, o.mx);
+        }
+        const Moments m = moments_of_shifted(c, block_total_shifted<PREP_NT / SB_WAVE>(v, wpart));
         if (tid == 0) {
             if (moments_out) *moments_out = m;
             else sigmoid_scalars<T>(m, stats);
@@ -574,6 +584,23 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
+        // host-model flavour: k_thc3 does k_prep's work itself (one dependent launch less on the critical path)
+        const int thc_threads = (H <= 16 && lc.thc_nt == 1024) ? 1024 : 512;
+        if (job.t0_fly && !lc.no_fold && sb_thc_can_fold(job.thc_ntx * job.thc_nty, nblk, lc.ncu, thc_threads)) {
+            DiagJob<T> fj = job;
+            fj.fold = 1;
+            fj.fold_partials = lc.partials;
+            fj.fold_nparts = reuse ? 0 : nblk;
+            fj.stats_out = (T *)lc.stats;
+            SB_EV_BEGIN(SB_PROF_THC);
+            if ((e = sb_launch_thc<T>(fj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+            SB_EV_END(SB_PROF_THC);
+            SB_EV_BEGIN(SB_PROF_WIND);
+            launch_wind<T>(job, lc.ncu, st);
+            SB_EV_END(SB_PROF_WIND);
+            if (lc.launches) *lc.launches += 3;
+            return hipGetLastError();
+        }
         SB_EV_BEGIN(SB_PROF_PREP);
         hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, reuse ? 0 : nblk, (T *)lc.stats, (Moments *)nullptr);
         SB_EV_END(SB_PROF_PREP);

@@ -33,6 +33,7 @@ struct SbLaunchCtx {
     int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
     bool reuse_stats;               // the sigmoid scalars in `stats` stand (static sigma): no moments, no merge
+    bool no_fold;                   // keep k_prep as a kernel of its own (sb_set_fold(ctx, 0): measurement and tests)
     int *launches;                  // += kernels enqueued by the call, or nullptr
 };
 
@@ -45,6 +46,8 @@ template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
 // tile size of the contrast kernel that will run for an LDS halo of H cells
 void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);
+// can k_thc3 take over k_prep's work (job.fold) for this many tiles, partial moments and workgroups?
+bool sb_thc_can_fold(int ntiles, int nparts, int nblocks, int threads);
 // the contrast kernel: reads the list of active tiles and the sigmoid scalars k_prep left
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStream_t st);   // nt: 512 or 1024 threads

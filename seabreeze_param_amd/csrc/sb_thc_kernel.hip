@@ -22,6 +22,9 @@
 #ifndef THC_SKIP
 #define THC_SKIP 0                // diagnostic builds only: bit 0 no sigmoid, 1 no scans, 2 no radius probes, 3 no sums, 4 no prefetch loads
 #endif
+#ifndef THC_T0_BATCH
+#define THC_T0_BATCH 1             // t0 of a wave's rows in one branch-free stretch (0: a wave-uniform branch per row)
+#endif
 #ifndef THC_SEARCH
 #define THC_SEARCH 1               // radius search on the count table: 0 two rounds of independent probes, 1 bisection
 #endif
@@ -263,7 +266,60 @@ __device__ __forceinline__ int sb_wave_max_to_last(int v) {
     return v;                                    // values are >= 0, lanes without a source contribute 0
 }
 
-template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF>     // WF: k_wind applies the update (job.wind_final)
+// exclusive prefix of one int per thread over an NT-thread workgroup; total in `total`.  Two barriers.
+template <int NT>
+__device__ __forceinline__ int thc_block_excl_scan(int v, int *s_w, int &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int incl = sb_wave_scan_add(v);
+    __syncthreads();
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    const int wt = lane < NT / SB_WAVE ? s_w[lane] : 0;
+    const int wincl = sb_wave_scan_add(wt);
+    total = __shfl(wincl, NT / SB_WAVE - 1);
+    return incl - v + __shfl(wincl, wv) - __shfl(wt, wv);
+}
+
+#define THC_MAXCNT 256            // FOLD: 64-bit words of the active-tile bit plane a workgroup can hold (the host checks)
+
+// FOLD: the tile of row-major rank r among the active tiles, or -1 past the last, from the bit plane in LDS (bit b of
+// word k = tile 64 k + b).  Popcounts, one wave scan per 64 words and ballots; wave-uniform result; every wave of the
+// workgroup computes the same.
+__device__ __forceinline__ int thc_fold_pick(const uint64_t *s_bits, int nwords, int r, int lane) {
+    int tile = -1, run = 0;
+#pragma unroll
+    for (int k = 0; k < THC_MAXCNT / SB_WAVE; ++k) {
+        if (k * SB_WAVE >= nwords) break;                        // wave-uniform
+        const uint64_t w = (k * SB_WAVE + lane < nwords) ? s_bits[k * SB_WAVE + lane] : 0ull;
+        const int pc = __popcll(w);
+        const int incl = sb_wave_scan_add(pc);
+        const int before = run + incl - pc;                      // active tiles before this word
+        run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
+        const uint64_t hit = __ballot(before <= r && r < before + pc);
+        if (hit) {                                               // wave-uniform; at most one lane of one k
+            const int src = __ffsll((unsigned long long)hit) - 1;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, src);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), src);
+            const uint64_t word = ((uint64_t)hi << 32) | lo;
+            const int n = r - __builtin_amdgcn_readlane(before, src);
+            // the n-th set bit of the word: lane j looks at bit j
+            const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
+            const uint64_t sel = __ballot(me);
+            tile = (k * SB_WAVE + src) * 64 + __ffsll((unsigned long long)sel) - 1;
+        }
+    }
+    return tile;
+}
+
+// FOLD (single-domain host-model calls, job.fold): no k_prep between k_scan and this kernel.  Every workgroup
+//   * turns k_scan's tile flags into a bit plane (ballots, one barrier) and finds the tiles of ranks blockIdx,
+//     blockIdx + G, ... in it with popcounts and ballots alone (row-major order, so the dealing of tiles to
+//     workgroups is exactly that of k_prep's list),
+//   * adds up k_scan's shifted sums of sigma in k_prep's order (bit-identical scalars in every thread of every
+//     workgroup) while its first tile's loads are in flight; workgroup 0 publishes the scalars,
+//   * and the last SB_SEG_PARTS workgroups -- the ones the dealing gives one tile fewer whenever it is uneven --
+//     compact one sub-list each of the segments that hold band cells for k_wind, after their tiles.
+template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF, bool FOLD = false>     // WF: k_wind applies the update (job.wind_final)
 __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, const T *__restrict__ stats, int G, DiagJob<T> job) {
     constexpr int NWV = NT / SB_WAVE;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
@@ -293,6 +349,9 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
                                                  // them while a wave that is ahead already stages tile i + 1
     __shared__ uint64_t s_word[TY];              // band bits of every tile row
     __shared__ unsigned short s_cell[TX * TY];   // the tile's band cells, compacted
+    __shared__ uint64_t s_bits[FOLD ? THC_MAXCNT : 1];           // FOLD: the active tiles as a bit plane
+    __shared__ Moments s_wpart[FOLD ? NT / SB_WAVE : 1];
+    __shared__ int s_scan[NT / SB_WAVE];
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -316,9 +375,50 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     // every line of the argument block is touched by the first batch of scalar loads (a later first touch would be
     // one more cold round trip): the two pointers the compiler would otherwise fetch where they are first used
     asm volatile("" ::"s"(job.tile_nnmax), "s"(job.counters));
-    const int cand0 = tile_list[1 + pos], cand1 = tile_list[1 + pos + G];
+    int cand0 = -1, cand1 = -1;
     T sd = T(0), rr = T(0);
-    if constexpr (FLY) { sd = stats[0]; rr = stats[1]; }
+    Moments pm = moments_empty();
+    double shift_c = 0.0;
+    int fold_nwords = 0;
+    if constexpr (!FOLD) {
+        cand0 = tile_list[1 + pos];
+        cand1 = tile_list[1 + pos + G];
+        if constexpr (FLY) { sd = stats[0]; rr = stats[1]; }
+    } else {
+        // -- the tile flags, NT at a time, as a bit plane in LDS: word c NWV + wv = the ballot of chunk c in wave wv,
+        //    i.e. bit b of word k is tile 64 k + b (row-major).  One load round, one barrier; from there on every
+        //    wave works for itself (identical results in all of them, no further exchange).
+        const int ntiles = job.thc_ntx * job.thc_nty;
+        const int nch = (ntiles + NT - 1) / NT;                  // nch * NWV <= THC_MAXCNT words (host)
+        if (job.fold_nparts > 0) {
+            if (tid < job.fold_nparts) pm = job.fold_partials[tid];
+            shift_c = (double)job.sigma[(size_t)g.h * g.nxh + g.h];
+        } else { sd = stats[0]; rr = stats[1]; }
+        unsigned mine = 0;
+        for (int base = 0; base < nch; base += 16) {             // 16 loads in flight (clamped, so none is conditional)
+            int f[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = (base + j) * NT + tid;
+                f[j] = job.tile_nnmax[i < ntiles ? i : ntiles - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = (base + j) * NT + tid;
+                mine |= (i < ntiles && f[j] != 0) ? 1u << (base + j) : 0u;
+            }
+        }
+        for (int c = 0; c < nch; ++c) {
+            const uint64_t b = __ballot((mine >> c) & 1u);
+            if (lane == 0) s_bits[c * NWV + wv] = b;
+        }
+        // the waves' totals of k_scan's shifted sums travel through the same barrier
+        if (job.fold_nparts > 0) wave_total_shifted_store(pm, s_wpart);
+        __syncthreads();
+        fold_nwords = nch * NWV;
+        cand0 = thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x, lane);
+        cand1 = thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + G, lane);
+    }
     const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
     ThcBufs<FLY> B;
     B.th = sb_make_rsrc(FLY ? (const void *)job.theta : (const void *)job.t0, fbytes);
@@ -340,10 +440,22 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
 #ifdef SB_STAMPS
     acc[13] = clock64() - t_last;              // first tile's loads issued
 #endif
+    if constexpr (FOLD) {
+        if (job.fold_nparts > 0) {                               // uniform
+            // k_scan's shifted sums, one per thread, added up in k_prep's order; every thread holds the totals and
+            // derives the scalars itself (identical bits everywhere); workgroup 0 publishes them
+            const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
+            T st4[4];
+            sigmoid_scalars<T>(m, st4);
+            sd = st4[0]; rr = st4[1];
+            if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
+        }
+    }
     __syncthreads();
     SB_T(0);                                   // prologue
 
     int par = 0;
+    int fold_it = 0;
     while (tile >= 0) {
         const int tyi = tile / ntx;
         const int x0 = (tile - tyi * ntx) * TX, y0 = tyi * TY;
@@ -372,6 +484,19 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
             int colC[NCH];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) { colA[ch] = 0.0; colL[ch] = 0.0; colC[ch] = 0; }
+            if constexpr (FLY && THC_T0_BATCH) {
+                // t0 of all the wave's rows in one branch-free stretch: the rows' polynomial chains are independent,
+                // and without a branch between them the scheduler interleaves them (two waves per SIMD hide little
+                // of a 13-deep chain of fp64 fmas).  One wave-uniform branch for the lot: a wave whose rows are all
+                // sea (z = 0 -> t0 = theta exactly) skips it.     ref :166-167
+                bool anyland = false;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) anyland |= R.zz[k] != T(0);
+                if (!(THC_SKIP & 1) && __ballot(anyland) != 0) {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) R.th[k] = sb_t0<T>(R.th[k], R.zz[k], R.sg[k], sd, rr);
+                }
+            }
 #pragma unroll
             for (int ri = 0; ri < RPW; ++ri) {
                 const int r = wv * RPW + ri;
@@ -383,7 +508,7 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
                     const bool ok = rowok && R.xcol[ch] >= 0;
                     const unsigned land = ok ? ((R.lw[k] >> (R.xcol[ch] & 31)) & 1u) : 0u;
                     T t0v = R.th[k];
-                    if constexpr (FLY) {
+                    if constexpr (FLY && !THC_T0_BATCH) {
                         // the sigmoid only where a lane of the wave stands on land (wave-uniform branch)   ref :166-167
                         if (!(THC_SKIP & 1) && __ballot(ok && R.zz[k] != T(0)) != 0) t0v = sb_t0<T>(R.th[k], R.zz[k], R.sg[k], sd, rr);
                     }
@@ -413,7 +538,8 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         ThcCols<NCH> Cn;
         if (PF && tile_after >= 0) thc_issue_begin<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile_after, R, Cn);
         pos += G;
-        next_tile = tile_after >= 0 ? tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
+        if constexpr (FOLD) { ++fold_it; next_tile = tile_after >= 0 ? thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + (fold_it + 1) * G, lane) : -1; }
+        else next_tile = tile_after >= 0 ? tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
         // ---- A2: band cells -> list; finished tables ---------------------------------------------------
         int total;
         {
@@ -689,6 +815,28 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         tile = tile_after;
         par ^= 1;
     }
+    if constexpr (FOLD) {
+        // ---- k_wind's segment lists: sub-list `part` holds the segments with band cells of its contiguous range of the
+        // band plane, in ascending order (exactly what k_prep writes) ----
+        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+        const unsigned cap = (unsigned)job.seg_cap;
+        for (int part = G - 1 - (int)blockIdx.x; part < SB_SEG_PARTS; part += G) {
+            if (part < 0) break;
+            const unsigned s0 = (unsigned)part * cap, s1 = min(s0 + cap, nseg);
+            const unsigned per = (cap + NT - 1) / NT;
+            const unsigned a0 = min(s0 + (unsigned)tid * per, s1), a1 = min(a0 + per, s1);
+            int cnt = 0;
+            for (unsigned sg = a0; sg < a1; ++sg) cnt += job.bandbits[sg] != 0 ? 1 : 0;
+            int total;
+            int at = thc_block_excl_scan<NT>(cnt, s_scan, total);
+            SbSegEntry *list = job.seg_list + (size_t)part * cap;
+            for (unsigned sg = a0; sg < a1; ++sg) {
+                const uint64_t w = job.bandbits[sg];
+                if (w) { SbSegEntry e; e.word = w; e.seg = sg; e.pad = 0; list[at++] = e; }
+            }
+            if (tid == 0) job.seg_count[part] = total;
+        }
+    }
 #ifdef SB_STAMPS
     if (tid == 0) {
         acc[9] = w_begin;
@@ -701,7 +849,8 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
 template <typename T, int TX, int TY, int H, int NT>
 static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
     const dim3 gr(nblocks), bl(NT);
-    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    if (job.t0_fly && job.wind_final && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
@@ -731,6 +880,13 @@ hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStrea
 }
 template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, int, hipStream_t);
 template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, int, hipStream_t);
+
+// can k_thc3 take over k_prep's work for this many tiles, partial moments and workgroups?  (threads: of its workgroups)
+bool sb_thc_can_fold(int ntiles, int nparts, int nblocks, int threads) {
+    if (threads != 512 && threads != 1024) return false;
+    const int nch = (ntiles + threads - 1) / threads;
+    return nch <= 32 && nch * (threads / SB_WAVE) <= THC_MAXCNT && nparts <= threads && nblocks >= 1;
+}
 
 void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty) {
     if (H <= 16) {

@@ -105,6 +105,10 @@ class Context:
         """512 or 1024 threads per contrast-kernel workgroup (tuning / test knob)."""
         self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
 
+    def set_fold(self, on: bool):
+        """k_prep's work inside the contrast kernel (default) or as a kernel of its own (measurement / test knob)."""
+        self._chk(self.lib.sb_set_fold(self.h, C.c_int(1 if on else 0)), "sb_set_fold")
+
     def set_static_sigma(self, on: bool):
         """Opt-in: sigma does not change between calls; its statistics are formed once (include/seabreeze_hip.h)."""
         self._chk(self.lib.sb_set_static_sigma(self.h, C.c_int(1 if on else 0)), "sb_set_static_sigma")

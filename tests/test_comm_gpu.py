@@ -105,7 +105,8 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
         ctx.close()
 
 
-def test_static_sigma_single_domain(oracles):
+@pytest.mark.parametrize("fold", [True, False], ids=["fold", "kprep"])
+def test_static_sigma_single_domain(oracles, fold):
     """sb_set_static_sigma on a single domain: the statistics of the first call stand while the same device
     array comes back, another array forms them anew, and results equal the default path's bit for bit."""
     from seabreeze_param_amd import synth
@@ -119,6 +120,7 @@ def test_static_sigma_single_domain(oracles):
     ctx = hip.Context(0)
     try:
         stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_fold(fold)
         z, mk, pd = dev(st.z), dev(cdist), dev(p)
         sg_a, sg_b = dev(st.sigma), dev(st.sigma * 1.7 + 3.0)
         runs = {}
@@ -134,7 +136,7 @@ def test_static_sigma_single_domain(oracles):
                                        vd.data_ptr(), thd.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
                                        *[s.data_ptr() for s in state], stream)
                 torch.cuda.synchronize()
-                assert ctx.last_step_report()["kernel_launches"] == 4          # k_scan, k_prep, k_thc3, k_wind
+                assert ctx.last_step_report()["kernel_launches"] == (3 if fold else 4)     # k_scan, [k_prep,] k_thc3, k_wind
                 outs.append([s.cpu().numpy().copy() for s in state])
             runs[static] = outs
         for a, b in zip(runs[False], runs[True]):
