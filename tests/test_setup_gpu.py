@@ -96,9 +96,9 @@ def test_get_dist_wide_window_lds_kernel(hipctx, oracles, kwin):
 
 
 @pytest.mark.parametrize("prec", [8, 4])
-@pytest.mark.parametrize("shape", [(258, 7), (513, 9), (256, 8), (255, 17), (64, 3), (5, 5), (1030, 25)])
+@pytest.mark.parametrize("shape", [(258, 7), (513, 9), (256, 16), (255, 17), (64, 3), (5, 5), (1030, 35)])
 def test_get_edges_ragged_blocks(hipctx, oracles, shape, prec):
-    """k_edges works on 256 x 8 blocks with a ring staged in LDS: sizes that leave partial blocks in both
+    """k_edges works on 256 x 16 blocks with a ring staged in LDS: sizes that leave partial blocks in both
     directions, both land rules and both boundary treatments, fractional land and ice."""
     nx, ny = shape
     dt, orc = (np.float64, oracles[8]) if prec == 8 else (np.float32, oracles[4])
