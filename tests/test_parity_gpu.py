@@ -307,6 +307,39 @@ def test_um_layout_halo2(hipctx, oracles, prec, flags):
     assert err == 1 and all(np.array_equal(a, b) for a, b in zip(sh, before))
 
 
+def test_um_layout_halo2_240_steps(hipctx, oracles):
+    """BASELINE configs[4] as a sequence: 240 model steps in the UM layout (small halo 2, large halo 5, UM level walk,
+    theta <- t0), the carried state (windspeed, winddir, thc, sb_con) threaded through, steps of 24 minutes so that
+    the 6-hourly refresh (ref: generic/sea_breeze_diag.f90:264) fires sixteen times.  The oracle runs the same
+    sequence; states are compared every 20 steps and at the end (an error would compound, so the last comparison
+    covers all 240)."""
+    nx, ny, nz, hs, hl = 96, 64, 4, 2, 5
+    dt, orc = np.float64, oracles[8]
+    flags = hip.SB_UM_THETA_TO_T0 | hip.SB_UM_LEVEL_WALK
+    st = synth.static_fields(nx + 2 * hl, ny + 2 * hl, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cd_l = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=9000.0, kwin=1)
+    cd_l = np.where(np.abs(cd_l) < 12000.0, np.sign(cd_l) * np.minimum(np.abs(cd_l), 179.0), cd_l).astype(dt)
+    inner = lambda a, h: np.ascontiguousarray(a[hl - h:a.shape[0] - (hl - h), hl - h:a.shape[1] - (hl - h)])
+    core = (slice(hl, hl + ny), slice(hl, hl + nx))
+    p = synth.pressure_3d(st, nz, dt)[:, core[0], core[1]].copy()
+    z_s, sg_s, m_s = inner(st.z, hs), inner(st.sigma, hs), inner(cd_l, hs)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    triggered = 0
+    for tn in range(1, 241):
+        th_l = synth.theta_step(st, tn, dt)
+        u, v = (a[:, core[0], core[1]].copy() for a in synth.wind_step(st, nz, tn, dt))
+        th_s = inner(th_l, hs)
+        orc.seabreeze_diag(1440.0, tn, p, u, v, th_s, m_s, z_s, sg_s, *so, halo=hs, bnd=2, level_rule=1)
+        assert hipctx.seabreeze_diag_um(1440.0, tn, p, u, v, th_s.copy(), z_s, sg_s, cd_l, *sh, halo_s=hs, halo_l=hl, flags=flags) == 0
+        triggered += int(np.count_nonzero(so[3]))
+        if tn % 20 == 0 or tn == 240:
+            for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+                _assert_close64(a, b, f"UM sequence tn={tn} {nm}")
+            assert np.array_equal(sh[3] != 0, so[3] != 0)
+    assert triggered > 0                                  # the sequence does trigger somewhere
+
+
 def test_search_radius_beyond_lds_halo(hipctx, oracles):
     """Radius hint 8 but radii up to ~13: cells past the LDS halo take the global-memory path
     and must give the same numbers."""
