@@ -14,6 +14,8 @@
 !               p(nx,ny,nz), then per step: theta(nx,ny) u(nx,ny,nz) v(nx,ny,nz)
 !   output.bin: cdist(nx,ny), then per step: sb_con windspeed winddir thc (nx,ny each)
 !   mode (optional):
+!     um                         the Unified Model hook's argument order and bounds (seabreeze_diag_um) on the
+!                                sub-domain the rim of the input fields leaves
 !     host                       the reference's call shape: host arrays in, host arrays out (default)
 !     dev                        the fields live on the device (sb_dev_alloc); per step only theta, u, v go up
 !                                and the four outputs come back; seabreeze_diag_dev
@@ -53,7 +55,7 @@ program dummy_model
   integer(4) :: hdr(4)
 
   if (command_argument_count() < 3) then
-    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps> [host | dev | band <rank> <nranks> <idfile>]'
+    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps> [host | dev | um | band <rank> <nranks> <idfile>]'
     error stop 2
   end if
   call get_command_argument(1, fin)
@@ -94,6 +96,8 @@ program dummy_model
     call run_device_resident()
   case ('band')
     call run_band()
+  case ('um')
+    call run_um()
   case default
     error stop 'unknown mode'
   end select
@@ -162,6 +166,44 @@ contains
     call sb_dev_free(d_mask); call sb_dev_free(d_z); call sb_dev_free(d_sg)
     call sb_dev_free(d_ws); call sb_dev_free(d_wd); call sb_dev_free(d_thc); call sb_dev_free(d_sb)
   end subroutine run_device_resident
+
+  !---------------------------------------------------------------------------
+  ! The Unified Model hook's argument list and bounds (ref: UM/vn10.7/sea_breeze_diag.F90:55-56,66-117):
+  ! the rim of the input fields serves as the ghost cells of a sub-domain -- theta, z, sigma with a small
+  ! halo of halo_size + 1 cells (the widest window of a coastal-band cell), the coast distance with a large
+  ! halo of halo_size + 3 -- and the diagnostic is called with (theta, z, sigma, mask) in the UM's order and
+  ! its `error` status.  Output: the sub-domain's fields, per step.
+  !---------------------------------------------------------------------------
+  subroutine run_um()
+    use sea_breeze_diag_mod, only : get_edges, get_dist, seabreeze_diag_um
+    integer :: hs, hl, nxi, nyi, error
+    real, allocatable :: p_i(:,:,:), u_i(:,:,:), v_i(:,:,:), th_s(:,:), z_s(:,:), sg_s(:,:)
+    real, allocatable :: ws_i(:,:), wd_i(:,:), thc_i(:,:), sb_i(:,:)
+    hs = halo_size + 1; hl = halo_size + 3
+    nxi = nx - 2*hl; nyi = ny - 2*hl
+    if (nxi < 1 .or. nyi < 1) error stop 'um mode: grid too small for the ghost frame'
+    call get_edges(mask, ice_frac, land_frac, halo_size)
+    call get_dist(mask, land_frac, lon, lat, 180, cdist, halo_size)
+    write (uout) cdist
+    allocate(p_i(nxi,nyi,nz), u_i(nxi,nyi,nz), v_i(nxi,nyi,nz))
+    allocate(th_s(nxi+2*hs,nyi+2*hs), z_s(nxi+2*hs,nyi+2*hs), sg_s(nxi+2*hs,nyi+2*hs))
+    allocate(ws_i(nxi,nyi), wd_i(nxi,nyi), thc_i(nxi,nyi), sb_i(nxi,nyi))
+    ws_i = 0.; wd_i = 0.; thc_i = 0.; sb_i = 0.
+    p_i = p(1+hl:nx-hl, 1+hl:ny-hl, :)
+    z_s = z(1+hl-hs:nx-hl+hs, 1+hl-hs:ny-hl+hs)
+    sg_s = sigma(1+hl-hs:nx-hl+hs, 1+hl-hs:ny-hl+hs)
+    do step = 1, nsteps
+      read (uin) theta, u, v
+      u_i = u(1+hl:nx-hl, 1+hl:ny-hl, :)
+      v_i = v(1+hl:nx-hl, 1+hl:ny-hl, :)
+      th_s = theta(1+hl-hs:nx-hl+hs, 1+hl-hs:ny-hl+hs)
+      call seabreeze_diag_um(timestep, step, p_i, u_i, v_i, th_s, z_s, sg_s, cdist, ws_i, wd_i, thc_i, sb_i, error)
+      if (error /= 0) error stop 'um mode: seabreeze_diag_um reported an error'
+      write (uout) sb_i, ws_i, wd_i, thc_i, th_s
+    end do
+    sb_con = 0.
+    sb_con(1+hl:nx-hl, 1+hl:ny-hl) = sb_i
+  end subroutine run_um
 
   !---------------------------------------------------------------------------
   ! one latitude band of a multi-GPU run

@@ -40,6 +40,8 @@ module sea_breeze_diag_mod
   private
   public :: seabreeze_diag, seabreeze_diag_status, get_edges, get_dist, sigmoid, sb_shutdown
   public :: band_seabreeze_diag, seabreeze_diag_dev, band_seabreeze_diag_dev
+  public :: seabreeze_diag_um, SB_UM_THETA_TO_T0, SB_UM_LEVEL_WALK
+  integer, parameter :: SB_UM_THETA_TO_T0 = 1, SB_UM_LEVEL_WALK = 2
 
 #ifdef SB_REAL8
   integer, parameter :: rk = c_double
@@ -50,6 +52,7 @@ module sea_breeze_diag_mod
 #define SB_BAND_DIAG      "sb_band_seabreeze_diag_f64"
 #define SB_DIAG_DEV       "sb_seabreeze_diag_f64_dev"
 #define SB_BAND_DIAG_DEV  "sb_band_seabreeze_diag_f64_dev"
+#define SB_DIAG_UM        "sb_seabreeze_diag_um_f64"
 #else
   integer, parameter :: rk = c_float
 #define SB_SEABREEZE_DIAG "sb_seabreeze_diag_f32"
@@ -59,6 +62,7 @@ module sea_breeze_diag_mod
 #define SB_BAND_DIAG      "sb_band_seabreeze_diag_f32"
 #define SB_DIAG_DEV       "sb_seabreeze_diag_f32_dev"
 #define SB_BAND_DIAG_DEV  "sb_band_seabreeze_diag_f32_dev"
+#define SB_DIAG_UM        "sb_seabreeze_diag_um_f32"
 #endif
 
   integer(c_int), parameter :: SB_BND_GLOBAL = 1, SB_BND_HALO = 2
@@ -78,6 +82,16 @@ module sea_breeze_diag_mod
       real(rk), intent(in) :: p(*), u(*), v(*), theta(*), mask(*), z(*), sigma(*)
       real(rk), intent(inout) :: ws(*), wd(*), thc(*), sb_con(*)
     end function
+    integer(c_int) function c_diag_um(ctx, timestep, tn, nx, ny, nz, halo_s, halo_l, p, u, v, theta, z, sigma, mask, &
+        ws, wd, thc, sb_con, flags, error) bind(C, name=SB_DIAG_UM)
+      import :: c_ptr, c_int, rk
+      type(c_ptr), value :: ctx
+      real(rk), value :: timestep
+      integer(c_int), value :: tn, nx, ny, nz, halo_s, halo_l, flags
+      real(rk), intent(in) :: p(*), u(*), v(*), z(*), sigma(*), mask(*)
+      real(rk), intent(inout) :: theta(*), ws(*), wd(*), thc(*), sb_con(*)
+      integer(c_int), intent(out) :: error
+    end function c_diag_um
     integer(c_int) function c_band_diag(ctx, timestep, tn, nx, ny, nz, halo, p, u, v, theta, mask, &
         z, sigma, ws, wd, thc, sb_con, tun) bind(C, name=SB_BAND_DIAG)
       import :: c_ptr, c_int, rk
@@ -178,6 +192,43 @@ contains
     error = c_seabreeze_diag(ctx, real(timestep, rk), int(timestep_number, c_int), nx, ny, nz, h, bnd, &
                              p, u, v, theta, mask, z, sigma, windspeed, winddir, thc, sb_con, c_null_ptr)
   end subroutine seabreeze_diag_status
+
+  !---------------------------------------------------------------------------
+  ! The Unified Model hook's argument list and field bounds
+  ! (ref: UM/vn10.7/sea_breeze_diag.F90:55-56,66-117): (theta, z, sigma, mask) in the UM's order, `error` last;
+  ! p, u, v and the four state fields on pdims/tdims (nx, ny[, nz]); theta, z, sigma on tdims_s (small halo) and
+  ! mask on tdims_l (large halo) -- the halo widths are read off the array shapes.  theta is intent(inout) as in
+  ! the UM copy: with SB_UM_THETA_TO_T0 in `flags` it comes back as t0 (:210-211); SB_UM_LEVEL_WALK selects the UM
+  ! copy's level rule (:265-274).  flags absent: both, i.e. the UM copy's behaviour.
+  !---------------------------------------------------------------------------
+  subroutine seabreeze_diag_um(timestep, timestep_number, &
+      p, u, v, theta, z, sigma, mask, windspeed, winddir, thc, sb_con, error, flags)
+    integer, intent(in) :: timestep_number
+    real, intent(in) :: timestep
+    real, intent(in), contiguous :: p(:,:,:), u(:,:,:), v(:,:,:), z(:,:), sigma(:,:), mask(:,:)
+    real, intent(inout), contiguous :: theta(:,:), sb_con(:,:), windspeed(:,:), winddir(:,:), thc(:,:)
+    integer, intent(out) :: error
+    integer, intent(in), optional :: flags
+    integer(c_int) :: nx, ny, nz, hs, hl, fl, err, rc
+    nx = size(p, 1); ny = size(p, 2); nz = size(p, 3)
+    error = 1
+    if (nx < 1 .or. ny < 1 .or. nz < 1) return               ! ref: UM copy :198-202
+    if (any(shape(u) /= shape(p)) .or. any(shape(v) /= shape(p))) return
+    if (any(shape(windspeed) /= [nx, ny]) .or. any(shape(winddir) /= [nx, ny]) .or. &
+        any(shape(thc) /= [nx, ny]) .or. any(shape(sb_con) /= [nx, ny])) return
+    hs = (size(theta, 1) - nx) / 2
+    hl = (size(mask, 1) - nx) / 2
+    if (hs < 0 .or. hl < hs) return
+    if (any(shape(theta) /= [nx + 2*hs, ny + 2*hs]) .or. any(shape(z) /= shape(theta)) .or. &
+        any(shape(sigma) /= shape(theta)) .or. any(shape(mask) /= [nx + 2*hl, ny + 2*hl])) return
+    fl = SB_UM_THETA_TO_T0 + SB_UM_LEVEL_WALK
+    if (present(flags)) fl = int(flags, c_int)
+    call ensure_ctx()
+    rc = c_diag_um(ctx, real(timestep, rk), int(timestep_number, c_int), nx, ny, nz, hs, hl, p, u, v, theta, z, sigma, &
+                   mask, windspeed, winddir, thc, sb_con, fl, err)
+    if (rc /= 0) call fail('seabreeze_diag_um', rc)
+    error = int(err)
+  end subroutine seabreeze_diag_um
 
   !---------------------------------------------------------------------------
   ! One step of a latitude band of a multi-GPU run (one process per GPU, sb_comm_init done).

@@ -335,11 +335,52 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_w, int &total) {
     return incl - v + __shfl(wincl, wv) - __shfl(wt, wv);
 }
 
+// Ordered compaction by one PREP_NT-thread workgroup: emit(rank, i) for every i in [0, n) with pred(i), rank = number
+// of earlier such i.  Items are taken PREP_NT at a time (coalesced, independent loads), a ballot per chunk and wave
+// gives the per-(chunk, wave) counts, one workgroup scan their prefix.  n <= 64 * PREP_NT; returns the total.
+#define PREP_MAXCH 64
+template <typename Pred, typename Emit>
+__device__ __forceinline__ int block_compact(int n, int *s_cnt, int *s_w, Pred pred, Emit emit) {
+    constexpr int NW = PREP_NT / SB_WAVE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nch = (n + PREP_NT - 1) / PREP_NT;
+    uint64_t mine = 0;
+    for (int c0 = 0; c0 < nch; c0 += 4) {                        // four independent (clamped) loads in flight
+        bool on[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (c0 + j) * PREP_NT + tid;
+            on[j] = pred(i < n ? i : n - 1) && i < n;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const uint64_t b = __ballot(on[j]);
+            mine |= on[j] ? 1ull << c : 0ull;
+            if (lane == 0 && c < nch) s_cnt[c * NW + wv] = __popcll(b);
+        }
+    }
+    __syncthreads();
+    const int v = tid < nch * NW ? s_cnt[tid] : 0;
+    int total;
+    const int excl = block_excl_scan(v, s_w, total);     // its barriers stand between the reads above and the writes below
+    if (tid < nch * NW) s_cnt[tid] = excl;
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int c = 0; c < nch; ++c) {
+        const bool on = (mine >> c) & 1ull;
+        const uint64_t b = __ballot(on);
+        if (on) emit(s_cnt[c * NW + wv] + __popcll(b & lt), c * PREP_NT + tid);
+    }
+    return total;
+}
+
 template <typename T>
 __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments *__restrict__ partials, int nparts,
                                                   T *__restrict__ stats, Moments *__restrict__ moments_out) {
     __shared__ Moments wpart[PREP_NT / SB_WAVE];
     __shared__ int s_w[PREP_NT / SB_WAVE];
+    __shared__ int s_cnt[PREP_MAXCH * (PREP_NT / SB_WAVE)];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
         if (nparts <= 0) return;
@@ -360,14 +401,19 @@ __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments 
     }
     if (blockIdx.x == 1) {
         const int ntiles = job.thc_ntx * job.thc_nty;
-        const int per = (ntiles + PREP_NT - 1) / PREP_NT;
-        const int t0 = tid * per, t1 = min(t0 + per, ntiles);
-        int cnt = 0;
-        for (int t = t0; t < t1; ++t) cnt += job.tile_nnmax[t] != 0 ? 1 : 0;
         int total;
-        int at = block_excl_scan(cnt, s_w, total);
-        for (int t = t0; t < t1; ++t)
-            if (job.tile_nnmax[t] != 0) job.tile_list[1 + at++] = t;
+        if (ntiles <= PREP_MAXCH * PREP_NT) {
+            total = block_compact(ntiles, s_cnt, s_w, [&](int t) { return job.tile_nnmax[t] != 0; },
+                                  [&](int rank, int t) { job.tile_list[1 + rank] = t; });
+        } else {                                     // more tiles than the ballot form holds: a serial run per thread
+            const int per = (ntiles + PREP_NT - 1) / PREP_NT;
+            const int t0 = tid * per, t1 = min(t0 + per, ntiles);
+            int cnt = 0;
+            for (int t = t0; t < t1; ++t) cnt += job.tile_nnmax[t] != 0 ? 1 : 0;
+            int at = block_excl_scan(cnt, s_w, total);
+            for (int t = t0; t < t1; ++t)
+                if (job.tile_nnmax[t] != 0) job.tile_list[1 + at++] = t;
+        }
         if (tid == 0) job.tile_list[0] = total;
         // the list ends in -1 entries, two per k_thc3 workgroup: a workgroup reads its first two positions before
         // it knows the count, and finds its end without it
@@ -377,17 +423,26 @@ __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments 
     const int part = (int)blockIdx.x - 2;
     const unsigned nseg = (unsigned)job.g.nyh * (unsigned)job.g.nw;
     const unsigned cap = (unsigned)job.seg_cap;
-    const unsigned s0 = (unsigned)part * cap, s1 = min(s0 + cap, nseg);
-    const unsigned per = (cap + PREP_NT - 1) / PREP_NT;
-    const unsigned a0 = min(s0 + (unsigned)tid * per, s1), a1 = min(a0 + per, s1);
-    int cnt = 0;
-    for (unsigned sg = a0; sg < a1; ++sg) cnt += job.bandbits[sg] != 0 ? 1 : 0;
-    int total;
-    int at = block_excl_scan(cnt, s_w, total);
+    const unsigned s0 = min((unsigned)part * cap, nseg), s1 = min(s0 + cap, nseg);
     SbSegEntry *list = job.seg_list + (size_t)part * cap;
-    for (unsigned sg = a0; sg < a1; ++sg) {
-        const uint64_t w = job.bandbits[sg];
-        if (w) { SbSegEntry e; e.word = w; e.seg = sg; e.pad = 0; list[at++] = e; }
+    int total;
+    if (cap <= (unsigned)(PREP_MAXCH * PREP_NT)) {
+        total = block_compact((int)(s1 - s0), s_cnt, s_w, [&](int i) { return job.bandbits[s0 + (unsigned)i] != 0; },
+                              [&](int rank, int i) {
+                                  SbSegEntry e;
+                                  e.word = job.bandbits[s0 + (unsigned)i]; e.seg = s0 + (unsigned)i; e.pad = 0;
+                                  list[rank] = e;
+                              });
+    } else {
+        const unsigned per = (cap + PREP_NT - 1) / PREP_NT;
+        const unsigned a0 = min(s0 + (unsigned)tid * per, s1), a1 = min(a0 + per, s1);
+        int cnt = 0;
+        for (unsigned sg = a0; sg < a1; ++sg) cnt += job.bandbits[sg] != 0 ? 1 : 0;
+        int at = block_excl_scan(cnt, s_w, total);
+        for (unsigned sg = a0; sg < a1; ++sg) {
+            const uint64_t w = job.bandbits[sg];
+            if (w) { SbSegEntry e; e.word = w; e.seg = sg; e.pad = 0; list[at++] = e; }
+        }
     }
     if (tid == 0) job.seg_count[part] = total;
 }

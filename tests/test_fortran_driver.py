@@ -152,3 +152,45 @@ def test_dummy_model_band_mode_one_rank_communicator(tmp_path, oracles, prec):
     n2 = nx * ny
     orc = oracles[prec]
     _check_against_oracle(raw[n2:], n2, _oracle_sequence(orc, st, p, steps, raw[:n2].reshape(ny, nx), prec), prec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [8, 4])
+def test_dummy_model_um_mode(tmp_path, oracles, prec):
+    """`dummy_model ... um`: seabreeze_diag_um -- the UM vn10.7 hook's dummy order (theta, z, sigma, mask, ..., error)
+    and bounds (small halo for theta/z/sigma, large halo for mask; ref: UM/vn10.7/sea_breeze_diag.F90:55-56,66-117),
+    its level walk and the in-place theta <- t0 -- against the oracle's raw-index flavour with the UM level rule."""
+    assert _built()
+    nx, ny, nz, halo, nsteps = 96, 72, 5, 2, 3
+    dt = np.float64 if prec == 8 else np.float32
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    st, p, steps = _write_input(fin, prec, nx, ny, nz, halo, nsteps)
+    r = subprocess.run([EXE[prec], str(fin), str(fout), str(nsteps), "um"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(fout, dtype=dt)
+    n2 = nx * ny
+    cdist = raw[:n2].reshape(ny, nx)
+    hs, hl = halo + 1, halo + 3
+    nxi, nyi = nx - 2 * hl, ny - 2 * hl
+    small = lambda a: np.ascontiguousarray(a[hl - hs:ny - hl + hs, hl - hs:nx - hl + hs])
+    core = lambda a: np.ascontiguousarray(a[..., hl:ny - hl, hl:nx - hl])
+    orc = oracles[prec]
+    so = [np.zeros((nyi, nxi), dt) for _ in range(4)]
+    per, ns = nxi * nyi, (nxi + 2 * hs) * (nyi + 2 * hs)
+    off = n2
+    for t, (th, u, v) in enumerate(steps, start=1):
+        orc.seabreeze_diag(1440.0, t, core(p), core(u), core(v), small(th), small(cdist), small(st.z), small(st.sigma), *so,
+                           halo=hs, bnd=2, level_rule=1)
+        sb, ws, wd, thc = (raw[off + i * per: off + (i + 1) * per].reshape(nyi, nxi) for i in range(4))
+        th_back = raw[off + 4 * per: off + 4 * per + ns].reshape(nyi + 2 * hs, nxi + 2 * hs)
+        off += 4 * per + ns
+        if prec == 8:
+            for a, b, nm in ((ws, so[0], "ws"), (wd, so[1], "wd"), (thc, so[2], "thc"), (sb, so[3], "sb_con")):
+                assert relerr(a, b, floor=1e-2) < 1e-7, (t, nm)
+        else:
+            assert relerr(ws, so[0], floor=1e-3) < 2e-6 and np.max(np.abs(thc - so[2])) < 2e-3
+        # theta came back as t0: unchanged over the sea (z = 0), lowered over high ground
+        zs, ths = small(st.z), small(th)
+        assert np.array_equal(th_back[zs == 0], ths[zs == 0])
+        assert np.all(th_back[zs > 0] >= ths[zs > 0])          # gmma < 0: t0 = theta - gmma z sigmoid >= theta
+    assert off == raw.size

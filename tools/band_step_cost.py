@@ -67,8 +67,16 @@ for tn in range(300, 320):
     ctx.seabreeze_diag_dev(dt, 1440.0, tn, nx, nyb, nz, h, hip.SB_BND_HALO, *args, stream)
 km, _ = ctx.profile_end()
 print("plain call kernels (us):", {k: round(v * 1e3, 1) for k, v in km.items()}, ctx.last_counters())
+print("plain call enqueues:", ctx.last_step_report())
 band = timed(lambda tn: ctx.band_seabreeze_diag_dev(dt, 1440.0, tn, nx, nyb, nz, h, *args, stream))
+rep = ctx.last_step_report()
 print(f"band of {nx}x{nyb}x{nz}, halo {h}: plain call {plain:.1f} us, band step (one-rank communicator) {band:.1f} us, "
-      f"band machinery {band - plain:.1f} us per step")
+      f"band machinery {band - plain:.1f} us per step; a band step enqueues {rep} (an interior rank of a multi-rank run: "
+      f"4 RCCL sends/receives in one group + 1 all-gather instead of the copy)")
+# opt-in: sigma's statistics formed once (sb_set_static_sigma): no moments pass, no all-gather, no merge after step 1
+ctx.set_static_sigma(True)
+band_s = timed(lambda tn: ctx.band_seabreeze_diag_dev(dt, 1440.0, tn, nx, nyb, nz, h, *args, stream))
+print(f"  with static sigma (opt-in): band step {band_s:.1f} us, enqueues {ctx.last_step_report()}")
+ctx.set_static_sigma(False)
 ctx.comm_finalize()
 ctx.close()
