@@ -117,7 +117,7 @@ def cpu_baseline_and_parity(st, cdist, p, u, v, thetas, nz, gpu_states, timestep
     else:
         # Single precision is checked against the DOUBLE-precision arithmetic of the reference on the same
         # (fp32-representable) inputs: the reference's own fp32 build sums up to (2*16+1)^2 temperatures near
-        # 290 K sequentially in fp32 and carries ~6e-4 K of rounding noise in thc (tools/fp32_tolerance_study.py),
+        # 290 K sequentially in fp32 and carries ~6e-4 K of rounding noise in thc (tests/fp32_tolerance_study.py),
         # more than the HIP path's error, so it cannot serve as the yardstick.  Tolerances as in
         # tests/test_parity_gpu.py::test_baseline_config3_fp32_vs_oracle.
         orc8 = Oracle(8, omp=True)
@@ -145,7 +145,7 @@ def cpu_baseline_and_parity(st, cdist, p, u, v, thetas, nz, gpu_states, timestep
         parity = {"max_err": worst, "tolerance": tol, "steps": [tn for tn, _ in gpu_states["steps"]],
                   "trigger_flips": flips, "triggered_cells_fp64": triggered,
                   "checker": "oracle/sb_oracle.f90 in DOUBLE precision on the same fp32-representable inputs (the reference's "
-                             "own fp32 arithmetic carries ~6e-4 K of window-sum noise: tools/fp32_tolerance_study.py)",
+                             "own fp32 arithmetic carries ~6e-4 K of window-sum noise: tests/fp32_tolerance_study.py)",
                   "ok": bool(all(worst[k] <= tol[k] for k in tol) and flips <= max(2, triggered // 2000))}
     # ---- timing -----------------------------------------------------------------------------------
     out = {}

@@ -6,7 +6,7 @@ For every output field of seabreeze_diag (generic flavour) the error of
 both against the reference's arithmetic in double precision on the same (fp32-representable) inputs, at N512, N1280
 and -- with --big -- N2560 (5120x3840, windows of up to 31 cells).  The oracle is the checker here, never the product.
 
-    python tools/fp32_tolerance_study.py [--big] [--out gpurun_out/fp32_tolerance.json]
+    python tests/fp32_tolerance_study.py [--big] [--out gpurun_out/fp32_tolerance.json]
 
 What to expect, and why: the reference re-sums a (2nn+1)^2 window of temperatures near 290 K sequentially in the
 working precision (generic/sea_breeze_diag.f90:192-208); in fp32 the running sum of a 33 x 33 window reaches 3e5, where
@@ -22,7 +22,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # the repository root
 from oracle.pyoracle import Oracle  # noqa: E402  (checker)
 from seabreeze_param_amd import hip, synth  # noqa: E402
 

@@ -526,7 +526,7 @@ def test_baseline_config3_fp32_vs_oracle(hipctx):
     in fp32 (running sums of 1e6 carry 0.06 K per bit), which costs it up to ~0.03 K in a window mean, while the HIP
     path keeps its window sums in fp64.  So the contrast is held to the fp64 oracle on the same (fp32) inputs
     (2e-4 K: what rounding t0 to fp32 costs) and only loosely to the fp32 oracle; the winds, which pass through no
-    window sum, are held to the fp32 oracle at 2e-6.  tools/fp32_tolerance_study.py tabulates all three."""
+    window sum, are held to the fp32 oracle at 2e-6.  tests/fp32_tolerance_study.py tabulates all three."""
     nx, ny, nz = 5120, 3840, 3
     dt = np.float32
     orc4, orc8 = _omp_oracle(4), _omp_oracle(8)
