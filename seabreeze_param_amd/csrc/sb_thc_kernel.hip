@@ -843,6 +843,9 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         acc[10] = wall_clock64();
         for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)blockIdx.x * SB_NSTAMP + i] = acc[i];
     }
+    // the same sums as every wave of the first 64 workgroups saw them (rows 1024 ..): where do waves wait for each other?
+    if (lane == 0 && blockIdx.x < 64)
+        for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)(1024 + blockIdx.x * NWV + wv) * SB_NSTAMP + i] = acc[i];
 #endif
 }
 

@@ -28,10 +28,12 @@ state = [np.zeros((ny, nx), dt) for _ in range(4)]
 for tn in (1, 2, 3):
     ctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *state)
 NWG, NS = 256, 16
-buf = (C.c_longlong * (NWG * NS))()
-rc = ctx.lib.sb_debug_stamps(ctx.h, buf, C.c_int(NWG))
+NROW = 1024 + 64 * 16
+buf = (C.c_longlong * (NROW * NS))()
+rc = ctx.lib.sb_debug_stamps(ctx.h, buf, C.c_int(NROW))
 assert rc == 0, rc
-s = np.frombuffer(buf, dtype=np.int64).reshape(NWG, NS)
+allrows = np.frombuffer(buf, dtype=np.int64).reshape(NROW, NS)
+s = allrows[:NWG]
 tiles = s[:, 8]
 print(f"{threads} threads; workgroups {NWG}, tiles per workgroup min {tiles.min()} mean {tiles.mean():.2f} max {tiles.max()} (total {tiles.sum()})")
 names = ["prologue", "prefetch wait", "A1 compute", "barrier 1", "A2 tables", "barrier 2", "A3 search"]
@@ -45,3 +47,11 @@ print(f"  total cycles per workgroup mean {tot.mean():.0f} max {tot.max()}; wall
       f"kernel span {s[:, 10].max() - s[:, 9].min()}")
 print(f"  prologue split (cycles since kernel start, mean): borders zeroed {s[:, 11].mean():.0f}, list entries + scalars arrived {s[:, 12].mean():.0f}, first tile issued {s[:, 13].mean():.0f}, barrier passed {s[:, 0].mean():.0f}")
 print(ctx.last_counters())
+# per wave (mean over the first 64 workgroups, cycles per tile): which waves arrive late at the barriers
+nwv = threads // 64
+pw = allrows[1024:1024 + 64 * nwv].reshape(64, nwv, NS).astype(np.float64)
+tl = np.maximum(s[:64, 8], 1)[:, None]
+print("  per wave, cycles per tile:  wave  pf-wait   A1   bar1    A2   bar2    A3")
+for w in range(nwv):
+    m = [(pw[:, w, i] / tl[:, 0]).mean() for i in range(1, 7)]
+    print(f"                              {w:3d}  " + " ".join(f"{x:6.0f}" for x in m))
