@@ -412,12 +412,11 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
             const uint64_t b = __ballot((mine >> c) & 1u);
             if (lane == 0) s_bits[c * NWV + wv] = b;
         }
-        // the waves' totals of k_scan's shifted sums travel through the same barrier
-        if (job.fold_nparts > 0) wave_total_shifted_store(pm, s_wpart);
         __syncthreads();
+        // only what the first tile's loads need stands before them (this code runs once, from a cold instruction
+        // cache): the second tile, the table borders and the statistics follow the issue
         fold_nwords = nch * NWV;
         cand0 = thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x, lane);
-        cand1 = thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + G, lane);
     }
     const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
     ThcBufs<FLY> B;
@@ -425,21 +424,31 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.t0, fbytes);
     B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.t0, fbytes);
     B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
-    for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * PC] = 0; }
-    for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+    if constexpr (!FOLD) {
+        for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * PC] = 0; }
+        for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+    }
 #ifdef SB_STAMPS
-    acc[11] = clock64() - t_last;              // LDS borders zeroed (no load waited for yet)
+    acc[11] = clock64() - t_last;              // (k_prep path: LDS borders zeroed, no load waited for yet)
 #endif
     int tile = __builtin_amdgcn_readfirstlane(cand0);
-    int next_tile = __builtin_amdgcn_readfirstlane(cand1);
 #ifdef SB_STAMPS
-    acc[12] = clock64() - t_last;              // first list entries and scalars have arrived
+    acc[12] = clock64() - t_last;              // first list entry has arrived
 #endif
     ThcRegs<T, NC, NCH, FLY> R;
     if (PF && tile >= 0) thc_issue<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, wv, R);
 #ifdef SB_STAMPS
     acc[13] = clock64() - t_last;              // first tile's loads issued
 #endif
+    if constexpr (FOLD) {
+        for (int i = tid; i < HT + 1; i += NT) { sA[i * P] = 0.0; sL[i * P] = 0.0; sC[i * PC] = 0; }
+        for (int i = tid; i < P; i += NT) { sA[i] = 0.0; sL[i] = 0.0; sC[i] = 0; }
+        cand1 = thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + G, lane);
+        // the waves' totals of k_scan's shifted sums travel through the barrier below
+        if (job.fold_nparts > 0) wave_total_shifted_store(pm, s_wpart);
+    }
+    int next_tile = __builtin_amdgcn_readfirstlane(cand1);
+    __syncthreads();
     if constexpr (FOLD) {
         if (job.fold_nparts > 0) {                               // uniform
             // k_scan's shifted sums, one per thread, added up in k_prep's order; every thread holds the totals and
@@ -451,7 +460,6 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
             if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
         }
     }
-    __syncthreads();
     SB_T(0);                                   // prologue
 
     int par = 0;
