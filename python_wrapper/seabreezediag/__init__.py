@@ -140,9 +140,11 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
     ws, wd = (np.array(state[k], dtype=np.float32, order="C") for k in ("ws", "wd"))
     thc = np.empty_like(ws)
 
-    has_time = np.ndim(v) > 3
-    nt = len(v) if has_time else 1
-    nlat, nlon = np.shape(t)[-2:]
+    # arrays or file variables (netCDF4 / scipy: they carry `shape`, and only slicing reads them)
+    shape_of = lambda a: tuple(a.shape) if hasattr(a, "shape") else np.shape(a)
+    has_time = len(shape_of(v)) > 3
+    nt = shape_of(v)[0] if has_time else 1
+    nlat, nlon = shape_of(t)[-2:]
     sb_all = np.zeros([nt, nlat, nlon])           # float64 like the reference's (ref :214)
     dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
 
@@ -151,6 +153,7 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
         if ci is not None:
             ice = ci[ts] if has_time else ci
             ice = ice.filled(0) if hasattr(ice, "filled") else ice
+            ice = np.asarray(ice, dtype=np.float32)          # what f2py would make of it (file data may be big-endian)
             dist = _coast_distance(lsm, ice, lon, lat)       # the reference recomputes it every step (:223-228); here: when ice changes
         return (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
 
@@ -198,20 +201,21 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
 
 def read_nc(fnv, fnu, fntheta, fnci, vv="v", vu="u", vtheta="t2m", vci="ci", vpres="pres", vtime="time"):
     """Open the four NetCDF inputs and return an object usable as ``diag(..., meta=...)``
-    (ref: python_wrapper/seabreezediag/__init__.py:53-89).  Needs netCDF4, which this image
-    does not ship; the import is deferred so the rest of the package works without it."""
-    import os
+    (ref: python_wrapper/seabreezediag/__init__.py:53-89): attributes ``u, v, theta, ci`` (the file variables, sliced
+    step by step by ``diag``), ``time`` (datetimes), ``pres`` (the level axis), ``dt`` (minutes between the first two
+    time slices) and ``nc`` (the open files, for the caller to close).  Files are read through ``ncio`` (netCDF4
+    where it can be imported, scipy's classic-format reader otherwise)."""
     from types import SimpleNamespace
 
-    from netCDF4 import Dataset, num2date
+    from . import ncio
 
     files = {"v": fnv, "u": fnu, "theta": fntheta, "ci": fnci}
     varname = {"v": vv, "u": vu, "theta": vtheta, "ci": vci}
-    meta = SimpleNamespace(nc={k: Dataset(os.path.expanduser(f)) for k, f in files.items()})
+    meta = SimpleNamespace(nc={k: ncio.open_dataset(f) for k, f in files.items()})
     for key, ds in meta.nc.items():
         setattr(meta, key, ds.variables[varname[key]])
     tvar = meta.nc["v"].variables[vtime]
-    meta.time = num2date(tvar[:], tvar.units)
-    meta.pres = meta.nc["v"].variables[vpres][:]
-    meta.dt = (meta.time[1] - meta.time[0]).seconds / 60.0
+    meta.time = ncio.num2date(tvar[:], tvar.units)
+    meta.pres = np.array(meta.nc["v"].variables[vpres][:])
+    meta.dt = (meta.time[1] - meta.time[0]).seconds / 60.0 if len(meta.time) > 1 else 0.0
     return meta

@@ -40,6 +40,13 @@ def hipctx():
     ctx.close()
 
 
+def gpu_visible():
+    """Is there an AMD GPU on this machine?  Asked of the kernel driver, not of torch: once another HIP runtime in the
+    process (libseabreeze_hip.so links ROCm's, torch ships its own) has initialised the device, torch.cuda.is_available()
+    can answer False on a GPU box."""
+    return os.path.exists("/dev/kfd")
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -42,8 +42,8 @@ def _built():
 
 @pytest.mark.skipif(not _built(), reason="fortran/build not made (run __graft_entry__.build())")
 def test_driver_fails_loudly_without_device(tmp_path):
-    import torch
-    if torch.cuda.is_available():
+    from conftest import gpu_visible
+    if gpu_visible():
         pytest.skip("a GPU is visible here")
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     _write_input(fin, 8, 96, 72, 2, 4, 1)

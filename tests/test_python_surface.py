@@ -207,8 +207,8 @@ def test_extension_reports_errors_instead_of_stopping_the_interpreter():
     message (and the Python layer raise), not end the process (the first version ran `error stop`)."""
     if not _built():
         pytest.skip("python_wrapper extension not built")
-    import torch
-    if torch.cuda.is_available():
+    from conftest import gpu_visible
+    if gpu_visible():
         pytest.skip("a GPU is visible here")
     seabreeze, sbd = _import_surface()
     lsm = np.zeros((8, 6), np.float32, order="F")
