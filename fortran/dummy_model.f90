@@ -14,6 +14,8 @@
 !               p(nx,ny,nz), then per step: theta(nx,ny) u(nx,ny,nz) v(nx,ny,nz)
 !   output.bin: cdist(nx,ny), then per step: sb_con windspeed winddir thc (nx,ny each)
 !   mode (optional):
+!     status                     the argument checks of seabreeze_diag_status / seabreeze_diag_um (error = 1 for
+!                                inconsistent shapes, before any device work: runs without a GPU)
 !     um                         the Unified Model hook's argument order and bounds (seabreeze_diag_um) on the
 !                                sub-domain the rim of the input fields leaves
 !     host                       the reference's call shape: host arrays in, host arrays out (default)
@@ -55,7 +57,7 @@ program dummy_model
   integer(4) :: hdr(4)
 
   if (command_argument_count() < 3) then
-    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps> [host | dev | um | band <rank> <nranks> <idfile>]'
+    print *, 'usage: dummy_model <input.bin> <output.bin> <nsteps> [host | dev | um | status | band <rank> <nranks> <idfile>]'
     error stop 2
   end if
   call get_command_argument(1, fin)
@@ -98,6 +100,8 @@ program dummy_model
     call run_band()
   case ('um')
     call run_um()
+  case ('status')
+    call check_status()
   case default
     error stop 'unknown mode'
   end select
@@ -204,6 +208,31 @@ contains
     sb_con = 0.
     sb_con(1+hl:nx-hl, 1+hl:ny-hl) = sb_i
   end subroutine run_um
+
+  !---------------------------------------------------------------------------
+  ! Argument checks of the status-returning entry points: they answer error = 1 before any device work
+  ! (ref: UM/vn10.7/sea_breeze_diag.F90:102,198-202), so this mode runs without a GPU as well.
+  !---------------------------------------------------------------------------
+  subroutine check_status()
+    use sea_breeze_diag_mod, only : seabreeze_diag_status, seabreeze_diag_um
+    real, allocatable :: th_big(:,:), mk_big(:,:), ws_small(:,:), mk_small(:,:), th_s(:,:), z_s(:,:), sg_s(:,:)
+    integer :: e_mixed, e_state, e_um
+    u = 0.; v = 0.; theta = 280.; cdist = 0.
+    ! the outline's own declaration: mask, theta (nx+halo_size, ny+halo_size) beside z, sigma (nx, ny)
+    ! (ref: generic/get_all_fields_mod.f90:17-19)
+    allocate(th_big(nx+halo_size, ny+halo_size), mk_big(nx+halo_size, ny+halo_size))
+    th_big = 280.; mk_big = 0.
+    call seabreeze_diag_status(timestep, 1, p, u, v, th_big, mk_big, z, sigma, windspeed, winddir, thc, sb_con, e_mixed)
+    ! a state field of another shape than p's horizontal extent
+    allocate(ws_small(nx-1, ny)); ws_small = 0.
+    call seabreeze_diag_status(timestep, 1, p, u, v, theta, cdist, z, sigma, ws_small, winddir, thc, sb_con, e_state)
+    ! UM bounds: the large halo (mask) must not be narrower than the small one (theta, z, sigma)
+    allocate(th_s(nx+4, ny+4), z_s(nx+4, ny+4), sg_s(nx+4, ny+4), mk_small(nx+2, ny+2))
+    th_s = 280.; z_s = 0.; sg_s = 1.; mk_small = 0.
+    call seabreeze_diag_um(timestep, 1, p, u, v, th_s, z_s, sg_s, mk_small, windspeed, winddir, thc, sb_con, e_um)
+    print '(a,3(1x,i0))', 'status:', e_mixed, e_state, e_um
+    write (uout) real(e_mixed), real(e_state), real(e_um)
+  end subroutine check_status
 
   !---------------------------------------------------------------------------
   ! one latitude band of a multi-GPU run

@@ -52,6 +52,20 @@ def test_driver_fails_loudly_without_device(tmp_path):
     assert "no CPU fallback" in (r.stdout + r.stderr)
 
 
+@pytest.mark.skipif(not _built(), reason="fortran/build not made (run __graft_entry__.build())")
+@pytest.mark.parametrize("prec", [8, 4])
+def test_status_entry_points_reject_inconsistent_shapes(tmp_path, prec):
+    """seabreeze_diag_status and seabreeze_diag_um answer error = 1 -- the UM copy's status for bad dimensions
+    (ref: UM/vn10.7/sea_breeze_diag.F90:102,198-202) -- for the outline's own mixed declaration (mask, theta with half
+    a halo beside interior-sized z, sigma; ref: generic/get_all_fields_mod.f90:17-19), for a state field of the wrong
+    shape and for a UM mask frame narrower than theta's, all before any device work (so this runs without a GPU)."""
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    _write_input(fin, prec, 96, 72, 2, 4, 1)
+    r = subprocess.run([EXE[prec], str(fin), str(fout), "1", "status"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "status: 1 1 1" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", [8, 4])
 def test_dummy_model_matches_oracle(tmp_path, oracles, prec):
