@@ -90,6 +90,12 @@ int  sb_set_tile_rows(sb_ctx *ctx, int rows);
 /* Threads of the contrast kernel's workgroups for halos up to 16: 512 (8 waves of up to 256 registers, the
    default) or 1024 (16 waves of up to 128).  A tuning and test knob: results never depend on it.       */
 int  sb_set_thc_threads(sb_ctx *ctx, int threads);
+/* Single-domain host-model calls: run the contrast kernel (VALU/LDS-bound; without its register prefetch, so that it
+   leaves registers free) beside the memory half of the level-search kernel (HBM-bound: p column walk, u and v at the
+   chosen level) on two streams, followed by a small kernel that derives the wind and applies the update; off (the
+   default, and the faster one as measured: DESIGN.md 2.0): one after the other.  A measurement and test knob:
+   results never depend on it.                                                                              */
+int  sb_set_overlap(sb_ctx *ctx, int on);
 /* Single-domain host-model calls let the contrast kernel merge k_scan's statistics, pick its tiles and compact
    k_wind's segment lists itself (on, the default) or leave that to a kernel of its own between k_scan and
    the contrast kernel (off).  A measurement and test knob: results never depend on it.                  */

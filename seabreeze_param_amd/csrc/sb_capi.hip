@@ -58,6 +58,7 @@ struct sb_ctx {
     bool stats_valid = false;
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
+    int overlap = 0;                    // sb_set_overlap(ctx, 1): k_thc3 and k_wind side by side on two streams
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
     // what the last diag / band step enqueued (sb_last_step_report)
@@ -198,7 +199,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.seg_cap = (int)seg_cap;
     // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc3)
     job.nws = job.nwd = nullptr;
-    if (!(phases == 3 && !c->gathered)) {
+    const bool overlap = c->overlap && phases == 3 && !c->gathered && job.flavour == SB_FLAVOUR_GENERIC;
+    if (!(phases == 3 && !c->gathered) || overlap) {
         if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         job.nws = (T *)c->nws.p;
@@ -234,6 +236,17 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
     lc.no_fold = c->no_fold != 0;
+    lc.overlap = overlap;
+    lc.aux = nullptr; lc.ev_fork = lc.ev_join = nullptr;
+    if (overlap) {
+        if (!c->aux_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        lc.aux = c->aux_stream; lc.ev_fork = c->ev_fork; lc.ev_join = c->ev_join;
+    }
+    job.no_prefetch = 0;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     int launched = 0;
     lc.launches = &launched;
@@ -1400,6 +1413,12 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
     }
     NCCLCHK(c, g_rccl.AllGather(mine5, gathered, 5, ncclDouble, (ncclComm_t)c->comm, st));
     c->rep_rccl += 1;
+    return SB_OK;
+}
+
+int sb_set_overlap(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->overlap = on ? 1 : 0;
     return SB_OK;
 }
 

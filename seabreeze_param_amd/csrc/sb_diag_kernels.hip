@@ -572,6 +572,104 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
 }
 
 // ------------------------------------------------------------------------------------
+// k_walk (overlap mode): k_wind's memory half only -- the level search down the p column and the loads of u, v at
+// that level -- with a register footprint small enough (launch bounds: 8 workgroups per CU) for its waves to live on
+// the registers k_thc3 leaves free.  It leaves u, v of the chosen level in nws / nwd; k_final turns them into speed
+// and direction.   ref: generic/sea_breeze_diag.f90:223 (or the UM walk, UM/...:265-274)
+// ------------------------------------------------------------------------------------
+template <typename T, int UN>
+__global__ __launch_bounds__(WIND_NT, 8) void k_walk(DiagJob<T> job) {
+    const Geo g = job.g;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * WIND_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * WIND_NT) job.next_flags[i] = 0;
+    const int cnt = lane < SB_SEG_PARTS ? job.seg_count[lane] : 0;
+    const int incl = sb_wave_scan_add(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, SB_SEG_PARTS - 1);
+    const int nwaves = gridDim.x * (WIND_NT / SB_WAVE);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6));
+    const size_t pl = (size_t)g.nx * g.ny;
+    const int nz = job.nz;
+    for (int e = gw; e < total; e += nwaves) {
+        const uint64_t hit = __ballot(lane < SB_SEG_PARTS && e < incl);
+        const int part = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
+        const int base = __shfl(incl, part) - __shfl(cnt, part);
+        const SbSegEntry cur = job.seg_list[(size_t)part * job.seg_cap + (e - base)];
+        if (!((cur.word >> lane) & 1ull)) continue;
+        const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
+        const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
+        const size_t o = (size_t)y * g.nx + x;
+        const T *pc = job.p + o;
+        int lev = 0;
+        if (job.level_rule == 0) {
+            T best = T(0);
+            for (int k0 = 0; k0 < nz; k0 += UN) {
+                T d[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) d[q] = sb_ld<T, true>(pc + (size_t)(k0 + q < nz ? k0 + q : nz - 1) * pl);
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q;
+                    const T a = fabs(d[q] - job.target_plev);
+                    if (k == 0) best = a;
+                    else if (k < nz && a < best) { best = a; lev = k; }
+                }
+            }
+        } else {
+            T diff = T(1000000.);
+            bool done = false;
+            for (int k0 = 0; k0 < nz && !done; k0 += UN) {
+                T d[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) d[q] = sb_ld<T, true>(pc + (size_t)(k0 + q < nz ? k0 + q : nz - 1) * pl);
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int k = k0 + q;
+                    const T a = fabs(d[q] - job.target_plev);
+                    if (!done && k < nz) {
+                        if (a <= diff) { lev = k; diff = a; }
+                        else done = true;
+                    }
+                }
+            }
+        }
+        job.nws[o] = job.u[(size_t)lev * pl + o];
+        job.nwd[o] = job.v[(size_t)lev * pl + o];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_final (overlap mode): wind speed and direction from the u, v k_walk left in nws / nwd (ref: generic/...:225-227),
+// then thresholds, scaling and state update of every band cell with this call's contrast (k_thc3 left it in thc)
+// (ref :235-266).
+// Same list-driven shape as k_wind: a wave per segment that holds band cells.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(WIND_NT) void k_final(DiagJob<T> job) {
+    const Geo g = job.g;
+    const int lane = threadIdx.x & 63;
+    const int cnt = lane < SB_SEG_PARTS ? job.seg_count[lane] : 0;
+    const int incl = sb_wave_scan_add(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, SB_SEG_PARTS - 1);
+    const int nwaves = gridDim.x * (WIND_NT / SB_WAVE);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6));
+    for (int e = gw; e < total; e += nwaves) {
+        const uint64_t hit = __ballot(lane < SB_SEG_PARTS && e < incl);
+        const int part = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
+        const int base = __shfl(incl, part) - __shfl(cnt, part);
+        const SbSegEntry cur = job.seg_list[(size_t)part * job.seg_cap + (e - base)];
+        if (!((cur.word >> lane) & 1ull)) continue;
+        const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
+        const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
+        const size_t o = (size_t)y * g.nx + x;
+        SbCellState<T> cs = sb_trigger_load<T>(job, o);
+        const T uu = cs.n_ws, vv = cs.n_wd;                      // k_walk left u, v of the chosen level there
+        cs.n_ws = sqrt(uu * uu + vv * vv);                        // ref :225
+        cs.n_wd = atan2(-uu, -vv) * T(57.2957);                   // ref :227, rad2deg (sic) :128
+        sb_trigger_update<T, false>(job, o, job.thc[o], cs);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -639,8 +737,34 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
-        // host-model flavour: k_thc3 does k_prep's work itself (one dependent launch less on the critical path)
         const int thc_threads = (H <= 16 && lc.thc_nt == 1024) ? 1024 : 512;
+        if (job.t0_fly && lc.overlap && job.nws && job.nwd && thc_threads == 512) {
+            // k_prep, then k_thc3 (enqueued first, so that its one workgroup per CU is resident when k_wind's
+            // fill the registers it leaves) and k_wind side by side, then the update
+            SB_EV_BEGIN(SB_PROF_PREP);
+            hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, reuse ? 0 : nblk, (T *)lc.stats, (Moments *)nullptr);
+            SB_EV_END(SB_PROF_PREP);
+            if ((e = hipEventRecord(lc.ev_fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(lc.aux, lc.ev_fork, 0)) != hipSuccess) return e;
+            DiagJob<T> tj = job;
+            tj.no_prefetch = 1;
+            SB_EV_BEGIN(SB_PROF_THC);
+            if ((e = sb_launch_thc<T>(tj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+            DiagJob<T> wj = job;
+            wj.wind_final = 0;
+            // 2 x 160 registers of k_thc3 leave 192 per SIMD lane: four k_walk waves of 40; two more workgroups per CU
+            // queue up for the CUs whose k_thc3 workgroup ends early
+            hipLaunchKernelGGL((k_walk<T, SB_WIND_UN>), dim3(lc.ncu * 6), dim3(WIND_NT), 0, lc.aux, wj);
+            if ((e = hipEventRecord(lc.ev_join, lc.aux)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, lc.ev_join, 0)) != hipSuccess) return e;
+            SB_EV_END(SB_PROF_THC);                              // k_thc3 and k_wind together
+            SB_EV_BEGIN(SB_PROF_WIND);
+            hipLaunchKernelGGL(k_final<T>, dim3(lc.ncu * 8), dim3(WIND_NT), 0, st, job);
+            SB_EV_END(SB_PROF_WIND);                             // k_final
+            if (lc.launches) *lc.launches += 5;
+            return hipGetLastError();
+        }
+        // host-model flavour: k_thc3 does k_prep's work itself (one dependent launch less on the critical path)
         if (job.t0_fly && !lc.no_fold && sb_thc_can_fold(job.thc_ntx * job.thc_nty, nblk, lc.ncu, thc_threads)) {
             DiagJob<T> fj = job;
             fj.fold = 1;

@@ -33,6 +33,12 @@ struct SbLaunchCtx {
     int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
     bool reuse_stats;               // the sigmoid scalars in `stats` stand (static sigma): no moments, no merge
+    // overlap mode (single-domain host-model calls): k_thc3 (VALU/LDS-bound, without its register prefetch) on the
+    // caller's stream and k_walk (k_wind's HBM-bound half: level search, u, v) on aux run side by side; k_final
+    // derives the wind and applies the update.
+    bool overlap;
+    hipStream_t aux;
+    hipEvent_t ev_fork, ev_join;
     bool no_fold;                   // keep k_prep as a kernel of its own (sb_set_fold(ctx, 0): measurement and tests)
     int *launches;                  // += kernels enqueued by the call, or nullptr
 };

@@ -319,7 +319,9 @@ __device__ __forceinline__ int thc_fold_pick(const uint64_t *s_bits, int nwords,
 //     workgroup) while its first tile's loads are in flight; workgroup 0 publishes the scalars,
 //   * and the last SB_SEG_PARTS workgroups -- the ones the dealing gives one tile fewer whenever it is uneven --
 //     compact one sub-list each of the segments that hold band cells for k_wind, after their tiles.
-template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF, bool FOLD = false>     // WF: k_wind applies the update (job.wind_final)
+// PFX false (job.no_prefetch): no register prefetch of the next tile -- 160 instead of 228 registers per lane, which
+// leaves room on every SIMD for k_wind's waves when the two kernels run side by side (sb_launch_diag, overlap mode).
+template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF, bool FOLD = false, bool PFX = true>     // WF: k_wind applies the update (job.wind_final)
 __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, const T *__restrict__ stats, int G, DiagJob<T> job) {
     constexpr int NWV = NT / SB_WAVE;
     constexpr int W = TX + 2 * H, HT = TY + 2 * H, P = W + 1;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     // The next tile's inputs are prefetched into registers a whole tile ahead -- except where a thread holds two
     // chunks of every row (halos of 24 and 32 cells): there the prefetch registers would spill, and the loads are
     // issued when the tile's turn comes.
-    constexpr bool PF = NCH == 1;
+    constexpr bool PF = PFX && NCH == 1;
     __shared__ double sA[(HT + 1) * P];          // SAT of (t0 - c0), every cell
     __shared__ double sL[(HT + 1) * P];          // SAT of (t0 - c0), land-side cells
     __shared__ unsigned short sC[(HT + 1) * PC]; // SAT of land-side count (its own pitch, see PC)
@@ -860,7 +862,8 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
 template <typename T, int TX, int TY, int H, int NT>
 static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
     const dim3 gr(nblocks), bl(NT);
-    if (job.t0_fly && job.wind_final && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    if (job.t0_fly && job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly && job.wind_final && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);

@@ -105,6 +105,10 @@ class Context:
         """512 or 1024 threads per contrast-kernel workgroup (tuning / test knob)."""
         self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
 
+    def set_overlap(self, on: bool):
+        """Contrast kernel and level-search kernel side by side on two streams (measurement / test knob)."""
+        self._chk(self.lib.sb_set_overlap(self.h, C.c_int(1 if on else 0)), "sb_set_overlap")
+
     def set_fold(self, on: bool):
         """k_prep's work inside the contrast kernel (default) or as a kernel of its own (measurement / test knob)."""
         self._chk(self.lib.sb_set_fold(self.h, C.c_int(1 if on else 0)), "sb_set_fold")

@@ -133,21 +133,24 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
 
 
 @pytest.fixture(params=[(64, 512, True), (48, 512, True), (32, 512, True), (48, 1024, True), (32, 1024, True),
-                        (48, 512, False), (32, 1024, False)],
+                        (48, 512, False), (32, 1024, False), (48, 512, "overlap"), (32, 512, "overlap")],
                 ids=["tiles32x64", "tiles32x48", "tiles32x32", "tiles32x48-1024thr", "tiles32x32-1024thr",
-                     "tiles32x48-kprep", "tiles32x32-1024thr-kprep"])
+                     "tiles32x48-kprep", "tiles32x32-1024thr-kprep", "tiles32x48-overlap", "tiles32x32-overlap"])
 def tile_rows(request, hipctx):
-    """Every height of the contrast kernel's LDS tiles, both of its workgroup sizes, and k_prep's work inside the
-    contrast kernel (the default for host-model calls on one domain) or as a kernel of its own: by default small
+    """Every height of the contrast kernel's LDS tiles, both of its workgroup sizes, k_prep's work inside the
+    contrast kernel (the default for host-model calls on one domain) or as a kernel of its own, and the overlap mode
+    (contrast kernel beside the level walk on two streams): by default small
     grids get the 32-row tiles and the benchmark grid the 48-row ones, so the oracle comparisons run under each."""
     rows, threads, fold = request.param
     hipctx.set_tile_rows(rows)
     hipctx.set_thc_threads(threads)
-    hipctx.set_fold(fold)
+    hipctx.set_fold(fold is True)
+    hipctx.set_overlap(fold == "overlap")      # contrast kernel and level walk side by side, then k_final
     yield rows
     hipctx.set_tile_rows(0)
     hipctx.set_thc_threads(512)
     hipctx.set_fold(True)
+    hipctx.set_overlap(False)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
