@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     ap.add_argument("--thc-threads", type=int, default=0, help="tuning: 512 or 1024 threads per k_thc3 workgroup")
+    ap.add_argument("--thc-prefetch", action="store_true", help="tuning: k_thc3 with its register prefetch of the next tile")
     ap.add_argument("--overlap", action="store_true", help="measurement: k_thc3 and k_walk side by side (sb_set_overlap(ctx, 1))")
     ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
     ap.add_argument("--static-sigma", action="store_true",
@@ -302,6 +303,8 @@ def main():
     ctx = hip.Context(local_rank)
     if args.thc_threads:
         ctx.set_thc_threads(args.thc_threads)
+    if args.thc_prefetch:
+        ctx.set_thc_prefetch(True)
     if args.no_fold:
         ctx.set_fold(False)
     if args.overlap:

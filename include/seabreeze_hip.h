@@ -87,9 +87,13 @@ int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
    while the grid has too few tiles to give every compute unit one), 32, 48 or 64 = forced.  A tuning
    and test knob: results never depend on it.                                          */
 int  sb_set_tile_rows(sb_ctx *ctx, int rows);
-/* Threads of the contrast kernel's workgroups for halos up to 16: 512 (8 waves of up to 256 registers, the
-   default) or 1024 (16 waves of up to 128).  A tuning and test knob: results never depend on it.       */
+/* Threads of the contrast kernel's workgroups for halos up to 16: 1024 (16 waves of up to 128 registers: the default, 0
+   selects it) or 512 (8 waves of up to 256).  A tuning and test knob: results never depend on it.                 */
 int  sb_set_thc_threads(sb_ctx *ctx, int threads);
+/* The contrast kernel may load the next tile into registers while it works on the current one (on) or load every tile
+   when its turn comes (off, the default: 100 instead of 230 registers per lane, and four waves per SIMD hide the loads
+   better than the prefetch did -- DESIGN.md 2.4).  A tuning and test knob: results never depend on it.           */
+int  sb_set_thc_prefetch(sb_ctx *ctx, int on);
 /* Single-domain host-model calls: run the contrast kernel (VALU/LDS-bound; without its register prefetch, so that it
    leaves registers free) beside the memory half of the level-search kernel (HBM-bound: p column walk, u and v at the
    chosen level) on two streams, followed by a small kernel that derives the wind and applies the update; off (the

@@ -51,7 +51,8 @@ struct sb_ctx {
     int radius_hint = 16;
     int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc2 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
-    int thc_nt = 512;           // threads of a k_thc3 workgroup (sb_set_tuning)
+    int thc_nt = 1024;          // threads of a k_thc3 workgroup (sb_set_thc_threads)
+    int thc_prefetch = 0;       // k_thc3 prefetches the next tile into registers (sb_set_thc_prefetch)
     // opt-in: sigma does not change between calls (sb_set_static_sigma): its statistics are kept from the first
     // complete call on the same array and k_scan stops reading it
     int static_sigma = 0;
@@ -246,7 +247,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
         }
         lc.aux = c->aux_stream; lc.ev_fork = c->ev_fork; lc.ev_join = c->ev_join;
     }
-    job.no_prefetch = 0;
+    job.no_prefetch = c->thc_prefetch ? 0 : 1;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     int launched = 0;
     lc.launches = &launched;
@@ -1053,8 +1054,14 @@ int sb_debug_stamps(sb_ctx *c, long long *host, int nwg) {
 
 int sb_set_thc_threads(sb_ctx *c, int threads) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    if (threads != 512 && threads != 1024) return fail(c, SB_ERR_ARG, "contrast-kernel workgroups have 512 or 1024 threads");
-    c->thc_nt = threads;
+    if (threads != 0 && threads != 512 && threads != 1024) return fail(c, SB_ERR_ARG, "contrast-kernel workgroups have 512 or 1024 threads");
+    c->thc_nt = threads ? threads : 1024;
+    return SB_OK;
+}
+
+int sb_set_thc_prefetch(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->thc_prefetch = on ? 1 : 0;
     return SB_OK;
 }
 

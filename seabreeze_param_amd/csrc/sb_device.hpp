@@ -114,7 +114,7 @@ __device__ __forceinline__ void wave_total_shifted_store(Moments v, Moments *wpa
 template <int NW>
 __device__ __forceinline__ Moments block_total_shifted_finish(const Moments *wpart) {
     Moments r = wpart[0];
-#pragma unroll
+#pragma unroll 4                                 // (all NW x 5 values at once would cost up to 160 registers)
     for (int w = 1; w < NW; ++w) {
         const Moments o = wpart[w];
         r.n += o.n; r.mean += o.mean; r.m2 += o.m2;

@@ -738,7 +738,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
         const int thc_threads = (H <= 16 && lc.thc_nt == 1024) ? 1024 : 512;
-        if (job.t0_fly && lc.overlap && job.nws && job.nwd && thc_threads == 512) {
+        if (job.t0_fly && lc.overlap && job.nws && job.nwd) {
             // k_prep, then k_thc3 (enqueued first, so that its one workgroup per CU is resident when k_wind's
             // fill the registers it leaves) and k_wind side by side, then the update
             SB_EV_BEGIN(SB_PROF_PREP);
@@ -749,7 +749,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             DiagJob<T> tj = job;
             tj.no_prefetch = 1;
             SB_EV_BEGIN(SB_PROF_THC);
-            if ((e = sb_launch_thc<T>(tj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+            if ((e = sb_launch_thc<T>(tj, H, lc.ncu, 512, st)) != hipSuccess) return e;   // 8 waves x 160 registers
             DiagJob<T> wj = job;
             wj.wind_final = 0;
             // 2 x 160 registers of k_thc3 leave 192 per SIMD lane: four k_walk waves of 40; two more workgroups per CU

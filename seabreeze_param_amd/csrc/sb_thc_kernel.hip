@@ -397,15 +397,15 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
             shift_c = (double)job.sigma[(size_t)g.h * g.nxh + g.h];
         } else { sd = stats[0]; rr = stats[1]; }
         unsigned mine = 0;
-        for (int base = 0; base < nch; base += 16) {             // 16 loads in flight (clamped, so none is conditional)
-            int f[16];
+        for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
+            int f[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const int i = (base + j) * NT + tid;
                 f[j] = job.tile_nnmax[i < ntiles ? i : ntiles - 1];
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const int i = (base + j) * NT + tid;
                 mine |= (i < ntiles && f[j] != 0) ? 1u << (base + j) : 0u;
             }
@@ -548,8 +548,9 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         ThcCols<NCH> Cn;
         if (PF && tile_after >= 0) thc_issue_begin<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile_after, R, Cn);
         pos += G;
-        if constexpr (FOLD) { ++fold_it; next_tile = tile_after >= 0 ? thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + (fold_it + 1) * G, lane) : -1; }
-        else next_tile = tile_after >= 0 ? tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
+        if constexpr (FOLD && PF) { ++fold_it; next_tile = tile_after >= 0 ? thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + (fold_it + 1) * G, lane) : -1; }
+        else if constexpr (!FOLD) next_tile = tile_after >= 0 ? tile_list[1 + pos + G] : -1;   // (past a -1 entry nothing is read) made scalar where consumed
+        // (FOLD without the prefetch: the tile after next is picked at the end of the iteration, where few registers are live)
         // ---- A2: band cells -> list; finished tables ---------------------------------------------------
         int total;
         {
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
         // above) and the other s_land buffer; its first barrier stands before any table or list write
         SB_T(6);                               // A3
         tile = tile_after;
+        if constexpr (FOLD && !PF) { ++fold_it; next_tile = tile >= 0 ? thc_fold_pick(s_bits, fold_nwords, (int)blockIdx.x + (fold_it + 1) * G, lane) : -1; }
         par ^= 1;
     }
     if constexpr (FOLD) {
@@ -862,7 +864,11 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
 template <typename T, int TX, int TY, int H, int NT>
 static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
     const dim3 gr(nblocks), bl(NT);
-    if (job.t0_fly && job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    if (job.t0_fly && job.wind_final && job.no_prefetch && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly && job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly && job.wind_final && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
     else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);

@@ -101,8 +101,12 @@ class Context:
         """0: automatic, 32 / 48 / 64: force the contrast kernel's tile height (tuning / test knob)."""
         self._chk(self.lib.sb_set_tile_rows(self.h, C.c_int(rows)), "sb_set_tile_rows")
 
+    def set_thc_prefetch(self, on: bool):
+        """Register prefetch of the next tile in the contrast kernel (tuning / test knob; default off)."""
+        self._chk(self.lib.sb_set_thc_prefetch(self.h, C.c_int(1 if on else 0)), "sb_set_thc_prefetch")
+
     def set_thc_threads(self, threads: int):
-        """512 or 1024 threads per contrast-kernel workgroup (tuning / test knob)."""
+        """512 or 1024 threads per contrast-kernel workgroup, 0 = default (1024) (tuning / test knob)."""
         self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
 
     def set_overlap(self, on: bool):

@@ -132,23 +132,27 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[(64, 512, True), (48, 512, True), (32, 512, True), (48, 1024, True), (32, 1024, True),
-                        (48, 512, False), (32, 1024, False), (48, 512, "overlap"), (32, 512, "overlap")],
-                ids=["tiles32x64", "tiles32x48", "tiles32x32", "tiles32x48-1024thr", "tiles32x32-1024thr",
-                     "tiles32x48-kprep", "tiles32x32-1024thr-kprep", "tiles32x48-overlap", "tiles32x32-overlap"])
+@pytest.fixture(params=[(64, 1024, True, False), (48, 1024, True, False), (32, 1024, True, False), (48, 512, True, False),
+                        (32, 512, True, True), (48, 512, True, True), (48, 1024, True, True), (64, 512, True, True),
+                        (48, 1024, False, False), (32, 512, False, True), (48, 1024, "overlap", False), (32, 512, "overlap", False)],
+                ids=["tiles32x64", "tiles32x48", "tiles32x32", "tiles32x48-512thr",
+                     "tiles32x32-512thr-prefetch", "tiles32x48-512thr-prefetch", "tiles32x48-prefetch", "tiles32x64-512thr-prefetch",
+                     "tiles32x48-kprep", "tiles32x32-512thr-prefetch-kprep", "tiles32x48-overlap", "tiles32x32-512thr-overlap"])
 def tile_rows(request, hipctx):
-    """Every height of the contrast kernel's LDS tiles, both of its workgroup sizes, k_prep's work inside the
-    contrast kernel (the default for host-model calls on one domain) or as a kernel of its own, and the overlap mode
-    (contrast kernel beside the level walk on two streams): by default small
+    """Every height of the contrast kernel's LDS tiles, both of its workgroup sizes, with and without its register
+    prefetch, k_prep's work inside the contrast kernel (the default for host-model calls on one domain) or as a kernel
+    of its own, and the overlap mode (contrast kernel beside the level walk on two streams): by default small
     grids get the 32-row tiles and the benchmark grid the 48-row ones, so the oracle comparisons run under each."""
-    rows, threads, fold = request.param
+    rows, threads, fold, prefetch = request.param
     hipctx.set_tile_rows(rows)
     hipctx.set_thc_threads(threads)
+    hipctx.set_thc_prefetch(prefetch)
     hipctx.set_fold(fold is True)
     hipctx.set_overlap(fold == "overlap")      # contrast kernel and level walk side by side, then k_final
     yield rows
     hipctx.set_tile_rows(0)
-    hipctx.set_thc_threads(512)
+    hipctx.set_thc_threads(0)
+    hipctx.set_thc_prefetch(False)
     hipctx.set_fold(True)
     hipctx.set_overlap(False)
 
@@ -491,7 +495,8 @@ def _omp_oracle(prec):
 @pytest.mark.parametrize("shape", [(2560, 1920, 56), (1024, 768, 56)], ids=["N1280x56", "N512x56"])
 def test_baseline_configs_fp64_vs_oracle(hipctx, shape):
     """BASELINE configs[2] (the headline: k_wind walking 56 levels in 7 full batches, 48-row k_thc3 tiles,
-    about 670 of them active) and configs[1], default tiles, both workgroup sizes of k_thc3: first step,
+    about 670 of them active) and configs[1], default tiles, both workgroup sizes of k_thc3 (the default one without, the
+    other with the register prefetch): first step,
     ordinary step and a step whose target_time branch fires (timestep 1440 s: tn = 15), all four outputs."""
     nx, ny, nz = shape
     dt = np.float64
@@ -501,19 +506,22 @@ def test_baseline_configs_fp64_vs_oracle(hipctx, shape):
     cdist = hipctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     p = synth.pressure_3d(st, nz, dt)
     so = _states(ny, nx, dt, 4)
-    sh = {512: _states(ny, nx, dt, 4), 1024: _states(ny, nx, dt, 4)}
+    # the default instance (1024 threads, no register prefetch) and the 512-thread instance with its prefetch
+    sh = {(1024, False): _states(ny, nx, dt, 4), (512, True): _states(ny, nx, dt, 4)}
     for tn in (1, 2, 15):
         th = synth.theta_step(st, tn, dt)
         u, v = synth.wind_step(st, nz, tn, dt)
         orc.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1, omp=True)
-        for threads, s4 in sh.items():
+        for (threads, prefetch), s4 in sh.items():
             hipctx.set_thc_threads(threads)
+            hipctx.set_thc_prefetch(prefetch)
             try:
                 hipctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *s4, halo=0, bnd=hip.SB_BND_GLOBAL)
             finally:
-                hipctx.set_thc_threads(512)
+                hipctx.set_thc_threads(0)
+                hipctx.set_thc_prefetch(False)
             for a, b, nm in zip(s4, so, ("ws", "wd", "thc", "sb_con")):
-                _assert_close64(a, b, f"{shape} threads={threads} tn={tn} {nm}")
+                _assert_close64(a, b, f"{shape} threads={threads} prefetch={prefetch} tn={tn} {nm}")
             assert np.array_equal(s4[3] != 0, so[3] != 0), (threads, tn)
         del u, v
     c = hipctx.last_counters()

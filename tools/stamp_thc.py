@@ -1,6 +1,6 @@
 """Diagnostic: where does a k_thc3 workgroup spend its cycles?  Needs `make -C seabreeze_param_amd/csrc stamps`.
 
-    SEABREEZE_HIP_LIB=$PWD/seabreeze_param_amd/libseabreeze_hip_stamps.so python tools/stamp_thc.py [nx ny nz [threads]]
+    SEABREEZE_HIP_LIB=$PWD/seabreeze_param_amd/libseabreeze_hip_stamps.so python tools/stamp_thc.py [nx ny nz [threads [prefetch]]]
 
 Thread 0 of every workgroup sums the shader clock over the phases of its tiles (diagnostic build only; the
 prefetch wait is made explicit there, which the real kernel does not do).  Shares, not absolute run time.
@@ -14,11 +14,13 @@ sys.path.insert(0, ".")
 from seabreeze_param_amd import hip, synth  # noqa: E402
 
 nx, ny, nz = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (2560, 1920, 8)
-threads = int(sys.argv[4]) if len(sys.argv) >= 5 else 512
+threads = int(sys.argv[4]) if len(sys.argv) >= 5 else 1024
+prefetch = len(sys.argv) >= 6 and sys.argv[5] == "prefetch"
 dt = np.float64
 st = synth.static_fields(nx, ny, dt)
 ctx = hip.Context()
 ctx.set_thc_threads(threads)
+ctx.set_thc_prefetch(prefetch)
 coast = ctx.get_edges(st.landfrac, st.icefrac)
 cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
 p = synth.pressure_3d(st, nz, dt)
