@@ -240,8 +240,9 @@ contains
   subroutine run_band()
     use sea_breeze_diag_mod, only : get_edges, get_dist, band_seabreeze_diag
     use halo_exchange_mod, only : swap_bounds
-    use sb_context_mod, only : sb_comm_get_unique_id, sb_comm_init, sb_comm_finalize
+    use sb_context_mod, only : sb_comm_get_unique_id, sb_comm_init, sb_comm_finalize, sb_last_step_report
     integer(c_signed_char) :: id(128)
+    integer :: n_launch, n_rccl, n_group, n_copy
     integer :: r0, r1, nyl, h, base, rem, uid, ios, tries
     real, allocatable :: th_b(:,:), mask_b(:,:), z_b(:,:), sg_b(:,:)
     real, allocatable :: p_b(:,:,:), u_b(:,:,:), v_b(:,:,:)
@@ -303,6 +304,8 @@ contains
     end do
     sb_con = 0.
     sb_con(:, r0:r1) = sb_b
+    call sb_last_step_report(n_launch, n_rccl, n_group, n_copy)
+    print '(a,4(1x,i0))', 'band step enqueued (launches, RCCL ops, RCCL groups, copies):', n_launch, n_rccl, n_group, n_copy
     call sb_comm_finalize()
   end subroutine run_band
 

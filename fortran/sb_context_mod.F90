@@ -22,6 +22,7 @@ module sb_context_mod
   private
   public :: sb_ctx, sb_ensure_ctx, sb_fail, sb_release_ctx
   public :: sb_comm_get_unique_id, sb_comm_init, sb_comm_finalize, sb_comm_active, sb_comm_rank
+  public :: sb_set_static_sigma, sb_last_step_report
   public :: sb_dev_alloc, sb_dev_free, sb_dev_upload, sb_dev_download, sb_device_synchronize
 
   type(c_ptr), save :: sb_ctx = c_null_ptr
@@ -57,6 +58,16 @@ module sb_context_mod
     integer(c_int) function c_comm_finalize(ctx) bind(C, name="sb_comm_finalize")
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function c_set_static_sigma(ctx, on) bind(C, name="sb_set_static_sigma")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: on
+    end function
+    integer(c_int) function c_last_step_report(ctx, report) bind(C, name="sb_last_step_report")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int), intent(out) :: report(4)
     end function
     integer(c_int) function c_comm_rank(ctx, rank, nranks) bind(C, name="sb_comm_rank")
       import :: c_ptr, c_int
@@ -173,6 +184,26 @@ contains
     if (rc /= 0) call sb_fail('sb_comm_rank', rc)
     rank = r; nranks = n
   end subroutine sb_comm_rank
+
+  !> Opt-in: the caller states that sigma (an ancillary field) does not change between calls; its statistics are
+  !! then formed (and, in a band run, gathered) in the first step only.  include/seabreeze_hip.h: sb_set_static_sigma.
+  subroutine sb_set_static_sigma(on)
+    logical, intent(in) :: on
+    integer(c_int) :: rc
+    call sb_ensure_ctx()
+    rc = c_set_static_sigma(sb_ctx, merge(1_c_int, 0_c_int, on))
+    if (rc /= 0) call sb_fail('sb_set_static_sigma', rc)
+  end subroutine sb_set_static_sigma
+
+  !> What the last diag call / band step enqueued: kernel launches, RCCL operations, RCCL groups, device copies.
+  subroutine sb_last_step_report(launches, rccl_ops, rccl_groups, copies)
+    integer, intent(out) :: launches, rccl_ops, rccl_groups, copies
+    integer(c_int) :: rc, rep(4)
+    call sb_ensure_ctx()
+    rc = c_last_step_report(sb_ctx, rep)
+    if (rc /= 0) call sb_fail('sb_last_step_report', rc)
+    launches = rep(1); rccl_ops = rep(2); rccl_groups = rep(3); copies = rep(4)
+  end subroutine sb_last_step_report
 
   !---------------------------------------------------------------------------
   ! device arrays
