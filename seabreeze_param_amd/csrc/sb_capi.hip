@@ -81,15 +81,13 @@ struct sb_ctx {
     bool have_last = false;
     // optional per-kernel HIP-event timing (sb_profile_begin / sb_profile_end)
     const Moments *gathered = nullptr;   // device array of per-band sigma moments (multi-GPU), or null
-    Moments *band_moments_out = nullptr; // set by the band step for its phase-1 call: where k_scan's moments go
-    hipEvent_t band_moments_event = nullptr;
     int ngathered = 0;
     std::vector<hipEvent_t> prof_ev;
     std::vector<unsigned> prof_mask;    // per profiled call: which kernels were launched
     int prof_calls = 0, prof_max = 0;
     // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
     hipStream_t aux_stream = nullptr;   // communication of a band step runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mom = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf band_mom;                    // [5 own moments | 5 x nranks gathered]
     void *rccl_lib = nullptr;
     void *comm = nullptr;
@@ -232,8 +230,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu; lc.thc_nt = c->thc_nt;
-    lc.moments_out = (phases & 1) ? c->band_moments_out : nullptr;
-    lc.moments_event = (phases & 1) ? c->band_moments_event : nullptr;
+    lc.moments_out = nullptr;        // (a band step forms its moments with k_stats on the communication stream)
+    lc.moments_event = nullptr;
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
     lc.no_fold = c->no_fold != 0;
@@ -249,6 +247,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     job.no_prefetch = c->thc_prefetch ? 0 : 1;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
+    job.gath = nullptr; job.ngath = 0;
     int launched = 0;
     lc.launches = &launched;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
@@ -318,9 +317,9 @@ int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, doubl
 template <typename T>
 int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream);
 
-// One model step of a latitude band: the communication (sigma moments all-gather, theta ghost
-// rows) runs on the context's second stream while k_scan and k_wind, which need neither, run
-// on the caller's stream; the two join before the statistics merge and k_thc2.
+// One model step of a latitude band: the communication (this band's sigma moments and their all-gather, theta's
+// ghost rows) runs on the context's second stream while k_scan, k_prep and k_wind, which need neither, run
+// on the caller's stream; the two join before k_thc3, which merges the gathered moments in its prologue.
 template <typename T>
 int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int halo, const T *p, const T *u,
                   const T *v, T *theta, const T *mask, const T *z, const T *sigma, T *ws, T *wd, T *thc, T *sb_con,
@@ -335,39 +334,32 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
-    if (!c->ev_mom) HIPCHK(c, hipEventCreateWithFlags(&c->ev_mom, hipEventDisableTiming));
     if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
     double *mine = (double *)c->band_mom.p, *gath = mine + 5;
     // static sigma (opt-in): the scalars of the first step stand, no moments, no all-gather, no merge
     const bool reuse = reuse_stats<T>(c, sigma, nx, ny, halo);
     c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;
-    // fork: everything that talks to the neighbours goes to the second stream.  The ghost rows of theta
-    // need nothing from this step, so they travel first, while this band's sigma moments are formed on
-    // the caller's stream; the all-gather follows them (every rank issues the two in this order).
+    // fork: everything that talks to the other ranks goes to the second stream, and starts at once.  This band's
+    // sigma moments are formed there by a small kernel pair of their own (k_stats, 5 MB at eight ranks) and gathered
+    // straight away, the ghost rows of theta follow (every rank issues the two RCCL operations in this order), while
+    // k_scan (without the statistics), k_prep and k_wind -- which need neither -- run on the caller's stream: the
+    // round trip of the all-gather is covered by them instead of starting only after k_scan and k_prep
+    // (measured, one-rank communicator: 61 -> see DESIGN.md 5).
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    if (!reuse) {
+        if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream))) return rc;
+        c->rep_launches += 2;
+        if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
+    }
     if ((rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream))) return rc;
-    // phase 1 on the caller's stream meanwhile: k_scan also forms this band's sigma moments, a one-workgroup
-    // merge publishes them (ev_mom), k_wind follows; the all-gather waits for ev_mom on the second stream
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
     const Moments *saved_g = c->gathered;
     const int saved_n = c->ngathered;
     c->gathered = (const Moments *)gath;
     c->ngathered = c->nranks;
-    c->band_moments_out = (Moments *)mine;
-    c->band_moments_event = c->ev_mom;
     rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
                                thc, sb_con, tun, (void *)st, 1);
-    c->band_moments_out = nullptr;
-    c->band_moments_event = nullptr;
-    if (!rc && !reuse) {
-        hipError_t e = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);
-        if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
-    }
-    if (!rc && !reuse) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
-    if (!rc) {
-        hipError_t e = hipEventRecord(c->ev_join, c->aux_stream);
-        if (e != hipSuccess) rc = hipfail(c, e, "hipEventRecord");
-    }
     if (!rc) {
         hipError_t e = hipStreamWaitEvent(st, c->ev_join, 0);
         if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
@@ -942,7 +934,6 @@ int sb_destroy(sb_ctx *c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_mom) (void)hipEventDestroy(c->ev_mom);
     if (c->band_mom.p) (void)hipFree(c->band_mom.p);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);

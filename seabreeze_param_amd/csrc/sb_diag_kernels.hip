@@ -821,9 +821,16 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
+        DiagJob<T> pj = job;
         if (gathered && !reuse) {
-            hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered, (T *)lc.stats);
-            ++nl;
+            if (job.t0_fly) {                                    // k_thc3 merges the gathered moments in its prologue
+                pj.gath = lc.gathered;
+                pj.ngath = lc.ngathered;
+                pj.stats_out = (T *)lc.stats;
+            } else {                                             // k_t0 needs the scalars first
+                hipLaunchKernelGGL(k_merge_moments<T>, dim3(1), dim3(SB_WAVE), 0, st, lc.gathered, lc.ngathered, (T *)lc.stats);
+                ++nl;
+            }
         }
         if (!job.t0_fly) {
             SB_EV_BEGIN(SB_PROF_T0);
@@ -832,7 +839,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             ++nl;
         }
         SB_EV_BEGIN(SB_PROF_THC);
-        if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+        if ((e = sb_launch_thc<T>(pj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
         ++nl;
     }

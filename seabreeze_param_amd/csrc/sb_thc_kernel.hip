@@ -354,6 +354,7 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     __shared__ uint64_t s_bits[FOLD ? THC_MAXCNT : 1];           // FOLD: the active tiles as a bit plane
     __shared__ Moments s_wpart[FOLD ? NT / SB_WAVE : 1];
     __shared__ int s_scan[NT / SB_WAVE];
+    __shared__ T s_sdr[2];                                       // band step: the sigmoid scalars the first wave derived
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -385,7 +386,24 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     if constexpr (!FOLD) {
         cand0 = tile_list[1 + pos];
         cand1 = tile_list[1 + pos + G];
-        if constexpr (FLY) { sd = stats[0]; rr = stats[1]; }
+        if constexpr (FLY) {
+            if (job.ngath > 0) {
+                // band step: the first wave merges the moments gathered from all ranks -- lane b takes rank b, then the
+                // wave tree of k_merge_moments, so every workgroup of every rank derives the same bits -- and leaves
+                // the scalars in LDS for the barrier that ends the prologue; workgroup 0 publishes them
+                if (wv == 0) {
+                    Moments m = moments_empty();
+                    for (int b = lane; b < job.ngath; b += SB_WAVE) m = moments_merge(m, job.gath[b]);
+                    m = wave_merge(m);
+                    if (lane == 0) {
+                        T st4[4];
+                        sigmoid_scalars<T>(m, st4);
+                        s_sdr[0] = st4[0]; s_sdr[1] = st4[1];
+                        if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
+                    }
+                }
+            } else { sd = stats[0]; rr = stats[1]; }
+        }
     } else {
         // -- the tile flags, NT at a time, as a bit plane in LDS: word c NWV + wv = the ballot of chunk c in wave wv,
         //    i.e. bit b of word k is tile 64 k + b (row-major).  One load round, one barrier; from there on every
@@ -451,6 +469,9 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     }
     int next_tile = __builtin_amdgcn_readfirstlane(cand1);
     __syncthreads();
+    if constexpr (!FOLD && FLY) {
+        if (job.ngath > 0) { sd = s_sdr[0]; rr = s_sdr[1]; }
+    }
     if constexpr (FOLD) {
         if (job.fold_nparts > 0) {                               // uniform
             // k_scan's shifted sums, one per thread, added up in k_prep's order; every thread holds the totals and

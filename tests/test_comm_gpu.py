@@ -97,8 +97,9 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
         # what a band step enqueues (one rank: the all-gather is a 40-byte copy, no neighbours to send to):
-        # ghost fill, k_scan, k_prep, k_wind, moments merge, k_thc3; with static sigma the merge and the copy go
-        assert reports[0] == dict(kernel_launches=6, rccl_ops=0, rccl_groups=0, d2d_copies=1)
+        # on the communication stream k_stats + its merge, the copy, the ghost fill; on the caller's k_scan, k_prep, k_wind,
+        # k_thc3 (which merges the gathered moments itself); with static sigma the statistics and the copy go
+        assert reports[0] == dict(kernel_launches=7, rccl_ops=0, rccl_groups=0, d2d_copies=1)
         later = dict(kernel_launches=5, rccl_ops=0, rccl_groups=0, d2d_copies=0) if static_sigma else reports[0]
         assert all(r == later for r in reports[1:]), reports
     finally:

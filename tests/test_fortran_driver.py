@@ -162,8 +162,8 @@ def test_dummy_model_band_mode_one_rank_communicator(tmp_path, oracles, prec):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert idf.exists() and idf.stat().st_size == 128
-    # one rank: ghost fill, k_scan, k_prep, k_wind, moments merge, k_thc3; the all-gather degenerates to a copy
-    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 6 0 0 1" in r.stdout, r.stdout
+    # one rank: k_stats + merge, ghost fill, k_scan, k_prep, k_wind, k_thc3; the all-gather degenerates to a copy
+    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 7 0 0 1" in r.stdout, r.stdout
     raw = np.fromfile(fout, dtype=dt)
     n2 = nx * ny
     orc = oracles[prec]
