@@ -168,8 +168,10 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const int nflag = tx * ty + 2;
     if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag) {
         if ((rc = ensure(c, c->tiles, (size_t)2 * nflag * sizeof(int)))) return rc;
+        // (in stream order: a plain hipMemset runs on the null stream, which the non-blocking streams kernels are
+        // enqueued on do not wait for -- a late memset could wipe flags k_scan had already raised)
         HIPCHK(c, hipDeviceSynchronize());
-        HIPCHK(c, hipMemset(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int)));
+        HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int), st));
         c->tiles_n = nflag;
         c->flag_parity = 0;
     }
@@ -917,7 +919,8 @@ int sb_create(sb_ctx **out, int device) {
               hipMalloc((void **)&c->seg_count, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
               hipMemset(c->seg_count, 0, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
               hipMemset(c->ticket, 0, sizeof(unsigned int)) == hipSuccess &&
-              hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess;
+              hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess &&
+              hipDeviceSynchronize() == hipSuccess;   // the null-stream memsets have landed before any other stream runs
     if (!ok) {
         sb_destroy(c);
         return fail(nullptr, SB_ERR_ALLOC, "context allocation failed");
