@@ -105,3 +105,24 @@ def test_split_rows_and_ghost_fill():
     loc[:, h:h + nx] = core
     bands.fill_ew_ghosts(loc, nx, h)
     assert np.array_equal(loc[:, :h], core[:, -h:]) and np.array_equal(loc[:, -h:], core[:, :h])
+
+
+def test_split_rows_properties():
+    """Any cost vector, any rank count: the bands are contiguous, cover every row once, respect the minimum height,
+    and every rank derives the same cuts (pure function of its arguments)."""
+    from hypothesis import given, settings, strategies as hs
+
+    @settings(max_examples=200, deadline=None)
+    @given(hs.integers(1, 12), hs.integers(1, 6), hs.integers(0, 2 ** 32 - 1), hs.sampled_from(["flat", "spike", "ramp", "zeros"]))
+    def check(world, min_rows, seed, kind):
+        rng = np.random.default_rng(seed)
+        ny = world * min_rows + int(rng.integers(0, 200))
+        cost = {"flat": np.ones(ny), "zeros": np.zeros(ny), "ramp": np.arange(ny, dtype=float),
+                "spike": np.where(rng.random(ny) > 0.95, 1000.0, 1.0)}[kind] * rng.random()
+        sp = bands.split_rows(ny, world, cost=cost, min_rows=min_rows)
+        assert len(sp) == world and sp[0][0] == 0 and sp[-1][1] == ny
+        assert all(a[1] == b[0] for a, b in zip(sp, sp[1:]))
+        assert all(b - a >= min_rows for a, b in sp)
+        assert sp == bands.split_rows(ny, world, cost=cost.copy(), min_rows=min_rows)
+
+    check()
