@@ -49,7 +49,7 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
-    int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc2 tile height (sb_set_tile_rows)
+    int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc3 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
     int thc_nt = 1024;          // threads of a k_thc3 workgroup (sb_set_thc_threads)
     int thc_prefetch = 0;       // k_thc3 prefetches the next tile into registers (sb_set_thc_prefetch)

@@ -1,23 +1,25 @@
 // sb_diag_kernels.hip -- the seabreeze_diag hot path as CDNA4 (gfx950) kernels.
 //
 // One call of seabreeze_diag / diag (ref: generic/sea_breeze_diag.f90:55-271,
-// python_wrapper/seabreezediag/seabreeze_diag_python.f90:49-285) is four launches on one
-// stream (five for the f2py flavour):
+// python_wrapper/seabreezediag/seabreeze_diag_python.f90:49-285) is three launches on one
+// stream for a host-model call on a single domain, four or five otherwise:
 //
-//   k_scan   one pass over sigma and mask: per-workgroup moments of sigma, the band and
+//   k_scan   one pass over sigma and mask: per-workgroup shifted sums of sigma, the band and
 //            land-side bit planes, tile flags, and the fill value for every cell outside
 //            the coastal band                                                  [HBM stream]
-//   k_prep   2 + SB_SEG_PARTS workgroups: the moments merged into the sigmoid scalars, the tile flags
-//            compacted into the list of active tiles (for k_thc3), the band plane into the
-//            list of 64-cell segments that hold band cells (for k_wind)        [tiny]
+//   k_prep   (f2py flavour, band steps, very large tile counts, sb_set_fold(ctx, 0); otherwise k_thc3 does
+//            this work itself) 2 + SB_SEG_PARTS workgroups: the sums merged into the sigmoid scalars, the
+//            tile flags compacted into the list of active tiles (for k_thc3), the band plane into the
+//            lists of 64-cell segments that hold band cells (for k_wind)      [tiny]
 //   k_t0     f2py flavour only: the t0 plane is an output there               [HBM stream]
 //   k_thc3   (sb_thc_kernel.hip) per active 32 x TY tile: t0 and its summed-area tables in
-//            LDS, two-round search for the window radius -> thc               [VALU + LDS]
+//            LDS, bisection for the window radius -> thc                      [VALU + LDS]
 //   k_wind   per listed segment: level nearest target_plev in the p column of every band
 //            cell, wind speed / direction, thresholds, scaling, state update   [HBM gather]
 //
 // A band step of a multi-GPU run launches k_wind before its ghost rows arrive (it then leaves
-// this call's wind for k_thc3, which applies thresholds and update itself).
+// this call's wind for k_thc3, which applies thresholds and update itself).  The overlap mode
+// (sb_set_overlap, a measured experiment, off by default) splits k_wind into k_walk || k_thc3 and k_final.
 // Memory-bound integer/fp64 work: no MFMA anywhere.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"

@@ -6,13 +6,13 @@
 // both classes; only the last square matters.  Here a tile of 32 x TY cells plus a halo of
 // H cells is held in LDS as three summed-area tables (all cells, land-side cells,
 // land-side count), after which any square costs four LDS reads per table and the
-// smallest valid radius is found by a two-round search (the "both classes present"
+// smallest valid radius is found by bisection on the count table (the "both classes present"
 // predicate is monotone in nn).  Sums are taken about a per-tile offset c0, which cancels
 // exactly in the difference of the two means and keeps the fp64 prefix sums small.
 //
-// One persistent workgroup per CU (k_thc3, below) works through the list of active tiles
-// k_prep compacted from the flags k_scan raised: tiles that do not touch the coastal band
-// (about 3 in 4) cost nothing.
+// One persistent workgroup per CU (k_thc3, below) works through the active tiles -- ranked by itself from the flags
+// k_scan raised (FOLD) or taken from the list k_prep compacted: tiles that do not touch the coastal band (about
+// 3 in 4) cost nothing.  Default instance: 1024 threads, every tile loaded when its turn comes (PFX = false).
 #include "sb_device.hpp"
 #include "sb_launch.hpp"
 
