@@ -258,9 +258,6 @@ def main():
                          "cannot be initialised ends the run with a non-zero exit code: there is no silent fallback.")
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
-    ap.add_argument("--thc-threads", type=int, default=0, help="tuning: 512 or 1024 threads per k_thc3 workgroup")
-    ap.add_argument("--thc-prefetch", action="store_true", help="tuning: k_thc3 with its register prefetch of the next tile")
-    ap.add_argument("--overlap", action="store_true", help="measurement: k_thc3 and k_walk side by side (sb_set_overlap(ctx, 1))")
     ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
     ap.add_argument("--static-sigma", action="store_true",
                     help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
@@ -301,14 +298,8 @@ def main():
     t_gen = time.perf_counter()
     st = synth.static_fields(nx, ny, dt)
     ctx = hip.Context(local_rank)
-    if args.thc_threads:
-        ctx.set_thc_threads(args.thc_threads)
-    if args.thc_prefetch:
-        ctx.set_thc_prefetch(True)
     if args.no_fold:
         ctx.set_fold(False)
-    if args.overlap:
-        ctx.set_overlap(True)
     if world > 1 and comm == "native":
         # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
         uid = [hip.comm_unique_id() if rank == 0 else None]
@@ -450,8 +441,7 @@ def main():
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
             "variant": ("static-sigma (opt-in; not the reference's per-call statistics)" if args.static_sigma else "default")
-                       + (", k_prep as its own kernel" if args.no_fold else "")
-                       + (", overlap mode: k_thc3 || k_walk, then k_final (kernel_ms: k_thc = the pair, k_wind = k_final)" if args.overlap else ""),
+                       + (", k_prep as its own kernel" if args.no_fold else ""),
             "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
             "multi_rank_rccl": "unmeasured on hardware so far (one GPU per box in the build pool)" if world == 1 else "this run",
             "input_gen_s": round(gen_s, 1),

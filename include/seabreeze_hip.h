@@ -80,27 +80,11 @@ int  sb_destroy(sb_ctx *ctx);
 const char *sb_last_error(const sb_ctx *ctx);        /* ctx may be NULL               */
 const char *sb_version(void);
 void sb_default_tunables(sb_tunables *t);
-/* Expected largest search radius of the land/sea window (selects the LDS tile halo;
-   results never depend on it -- cells that need more take a global-memory path).   */
+/* Expected largest search radius of the land/sea window: up to 16 the marching-strip contrast
+   kernel runs (LDS halo 16), beyond it the tile kernel with a halo of 24 or 32 cells; results never
+   depend on it -- cells that need more take a global-memory path.                    */
 int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
-/* Rows of the contrast kernel's LDS tiles for halos up to 16: 0 = chosen from the grid size (48, or 32
-   while the grid has too few tiles to give every compute unit one), 32, 48 or 64 = forced.  A tuning
-   and test knob: results never depend on it.                                          */
-int  sb_set_tile_rows(sb_ctx *ctx, int rows);
-/* Threads of the contrast kernel's workgroups for halos up to 16: 1024 (16 waves of up to 128 registers: the default, 0
-   selects it) or 512 (8 waves of up to 256).  A tuning and test knob: results never depend on it.                 */
-int  sb_set_thc_threads(sb_ctx *ctx, int threads);
-/* The contrast kernel may load the next tile into registers while it works on the current one (on) or load every tile
-   when its turn comes (off, the default: 100 instead of 230 registers per lane, and four waves per SIMD hide the loads
-   better than the prefetch did -- DESIGN.md 2.4).  A tuning and test knob: results never depend on it.           */
-int  sb_set_thc_prefetch(sb_ctx *ctx, int on);
-/* Single-domain host-model calls: run the contrast kernel (VALU/LDS-bound; without its register prefetch, so that it
-   leaves registers free) beside the memory half of the level-search kernel (HBM-bound: p column walk, u and v at the
-   chosen level) on two streams, followed by a small kernel that derives the wind and applies the update; off (the
-   default, and the faster one as measured: DESIGN.md 2.0): one after the other.  A measurement and test knob:
-   results never depend on it.                                                                              */
-int  sb_set_overlap(sb_ctx *ctx, int on);
-/* Single-domain host-model calls let the contrast kernel merge k_scan's statistics, pick its tiles and compact
+/* Single-domain host-model calls let the strip contrast kernel merge k_scan's statistics and compact
    k_wind's segment lists itself (on, the default) or leave that to a kernel of its own between k_scan and
    the contrast kernel (off).  A measurement and test knob: results never depend on it.                  */
 int  sb_set_fold(sb_ctx *ctx, int on);

@@ -49,24 +49,21 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
-    int tile_rows = 0;          // 0: automatic; 32 / 48 / 64: forced k_thc3 tile height (sb_set_tile_rows)
     int ncu = 256;              // compute units of the device
-    int thc_nt = 1024;          // threads of a k_thc3 workgroup (sb_set_thc_threads)
-    int thc_prefetch = 0;       // k_thc3 prefetches the next tile into registers (sb_set_thc_prefetch)
     // opt-in: sigma does not change between calls (sb_set_static_sigma): its statistics are kept from the first
     // complete call on the same array and k_scan stops reading it
     int static_sigma = 0;
     bool stats_valid = false;
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
-    int overlap = 0;                    // sb_set_overlap(ctx, 1): k_thc3 and k_wind side by side on two streams
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
+    int stats_ngathered = 0;            // bands whose moments the kept scalars were merged from (0: this domain's own)
     // what the last diag / band step enqueued (sb_last_step_report)
     int rep_launches = 0, rep_rccl = 0, rep_groups = 0, rep_copies = 0;
     // workspace (grow-only)
     DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps;
-    int tiles_n = 0, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
+    int tiles_n = 0, tiles_strip = -1, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
     unsigned int *ticket = nullptr;
@@ -145,7 +142,8 @@ int pick_halo(const sb_ctx *c) {
 template <typename T>
 static bool reuse_stats(const sb_ctx *c, const T *sigma, int nx, int ny, int halo) {
     return c->static_sigma && c->host_depth == 0 && c->stats_valid && c->stats_sigma == (const void *)sigma && c->stats_dims[0] == nx &&
-           c->stats_dims[1] == ny && c->stats_dims[2] == halo && c->stats_dims[3] == (int)sizeof(T);
+           c->stats_dims[1] == ny && c->stats_dims[2] == halo && c->stats_dims[3] == (int)sizeof(T) &&
+           c->stats_ngathered == (c->gathered ? c->ngathered : 0);   // single-domain scalars are not a band run's
 }
 
 // Prepare workspace + job; enqueue the kernels of one diag call.
@@ -158,38 +156,49 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->bandbits, nbits))) return rc;
     if ((rc = ensure(c, c->clsbits, nbits))) return rc;
     const int H = pick_halo(c);
-    int txw, tyrows;
-    sb_thc_tile_shape(H, g.nx, g.rows, c->ncu, &txw, &tyrows);
-    if (H > 8 && H <= 16 && c->tile_rows) tyrows = c->tile_rows;
-    const int tx = (g.nx + txw - 1) / txw, ty = (g.rows + tyrows - 1) / tyrows;
+    // contrast kernel: marching strips (32 owned longitudes x 16-row blocks, flags strip-major with a virtual block
+    // above and below every strip) for LDS halos up to 16 cells, LDS tiles (row-major flags) beyond
+    int txw, tyrows, tx, ty;
+    const bool strip = H <= 16 && sb_strip_shape(g.nx, g.rows, &tx, &ty);
+    if (strip) { txw = 32; tyrows = 16; }
+    else {
+        sb_thc_tile_shape(H > 16 ? H : 24, &txw, &tyrows);
+        tx = (g.nx + txw - 1) / txw; ty = (g.rows + tyrows - 1) / tyrows;
+    }
+    const int Hk = strip ? 16 : (H > 16 ? H : 24);   // halo of the kernel that runs
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
     // raises flags in this call's buffer, k_wind clears the other one for the next call, so no
     // memset sits on the critical path and the last call's values stay readable.
-    const int nflag = tx * ty + 2;
-    if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag) {
+    const int ntile = strip ? tx * (ty + 2) : tx * ty;
+    const int nflag = ntile + 2;
+    if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag || c->tiles_strip != (strip ? 1 : 0)) {
         if ((rc = ensure(c, c->tiles, (size_t)2 * nflag * sizeof(int)))) return rc;
         // (in stream order: a plain hipMemset runs on the null stream, which the non-blocking streams kernels are
         // enqueued on do not wait for -- a late memset could wipe flags k_scan had already raised)
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int), st));
         c->tiles_n = nflag;
+        c->tiles_strip = strip ? 1 : 0;
         c->flag_parity = 0;
     }
     int *flags_now = (int *)c->tiles.p + (size_t)c->flag_parity * nflag;
     int *flags_next = (int *)c->tiles.p + (size_t)(1 - c->flag_parity) * nflag;
     job.thc_ty = tyrows; job.thc_ntx = tx; job.thc_nty = ty;
     job.thc_txs = txw == 32 ? 5 : 6;
+    job.strip = strip ? 1 : 0;
+    if (strip) { job.tile_sx = ty + 2; job.tile_sy = 1; job.tile_off = 1; }
+    else { job.tile_sx = 1; job.tile_sy = tx; job.tile_off = 0; }
     job.bandbits = (uint64_t *)c->bandbits.p;
     job.clsbits = (uint64_t *)c->clsbits.p;
     job.stats = (const T *)c->stats;
     job.tile_nnmax = flags_now;
-    job.counters = flags_now + (size_t)tx * ty;
+    job.counters = flags_now + (size_t)ntile;
     job.ticket = (int *)c->ticket;
     job.next_flags = flags_next;
     job.next_flags_n = nflag;
     // the lists k_prep compacts: active tiles (k_thc3) and segments that hold band cells (k_wind)
     // (padded: a k_thc3 workgroup loads its first two candidate entries before it knows how many there are)
-    if ((rc = ensure(c, c->tile_list, ((size_t)tx * ty + (size_t)2 * c->ncu + 2) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->tile_list, ((size_t)ntile + (size_t)2 * c->ncu + 2) * sizeof(int)))) return rc;
     job.tile_pad = 2 * c->ncu;
     const size_t nseg = (size_t)g.nyh * g.nw;
     const size_t seg_cap = (nseg + SB_SEG_PARTS - 1) / SB_SEG_PARTS;
@@ -200,8 +209,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.seg_cap = (int)seg_cap;
     // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc3)
     job.nws = job.nwd = nullptr;
-    const bool overlap = c->overlap && phases == 3 && !c->gathered && job.flavour == SB_FLAVOUR_GENERIC;
-    if (!(phases == 3 && !c->gathered) || overlap) {
+    if (!(phases == 3 && !c->gathered)) {
         if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         job.nws = (T *)c->nws.p;
@@ -231,40 +239,31 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
         lc.prof = &c->prof_ev[(size_t)SB_PROF_EVENTS * c->prof_calls++];
     }
     lc.partials = c->partials; lc.stats = c->stats;
-    lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu; lc.thc_nt = c->thc_nt;
+    lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
     lc.moments_out = nullptr;        // (a band step forms its moments with k_stats on the communication stream)
     lc.moments_event = nullptr;
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
     lc.no_fold = c->no_fold != 0;
-    lc.overlap = overlap;
-    lc.aux = nullptr; lc.ev_fork = lc.ev_join = nullptr;
-    if (overlap) {
-        if (!c->aux_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        lc.aux = c->aux_stream; lc.ev_fork = c->ev_fork; lc.ev_join = c->ev_join;
-    }
-    job.no_prefetch = c->thc_prefetch ? 0 : 1;
+    job.no_prefetch = 1;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     job.gath = nullptr; job.ngath = 0;
     int launched = 0;
     lc.launches = &launched;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
-    HIPCHK(c, sb_launch_diag<T>(job, H, lc));
+    HIPCHK(c, sb_launch_diag<T>(job, Hk, lc));
     c->rep_launches += launched;
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
     if (c->static_sigma && c->host_depth == 0 && !lc.reuse_stats) {
         c->stats_valid = true;
         c->stats_sigma = (const void *)job.sigma;
         c->stats_dims[0] = g.nx; c->stats_dims[1] = g.ny; c->stats_dims[2] = g.h; c->stats_dims[3] = (int)sizeof(T);
+        c->stats_ngathered = c->gathered ? c->ngathered : 0;
     }
     c->last_flags = flags_now;
     c->flag_parity = 1 - c->flag_parity;
     c->last_g = g;
-    c->last_tiles = tx * ty;
+    c->last_tiles = ntile;
     c->have_last = true;
     return SB_OK;
 }
@@ -338,6 +337,11 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     }
     if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
     double *mine = (double *)c->band_mom.p, *gath = mine + 5;
+    // (the reuse key tells single-domain scalars from a band run's: the gathered moments are in place before it is read)
+    const Moments *saved_g = c->gathered;
+    const int saved_n = c->ngathered;
+    c->gathered = (const Moments *)gath;
+    c->ngathered = c->nranks;
     // static sigma (opt-in): the scalars of the first step stand, no moments, no all-gather, no merge
     const bool reuse = reuse_stats<T>(c, sigma, nx, ny, halo);
     c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;
@@ -345,27 +349,22 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     // sigma moments are formed there by a small kernel pair of their own (k_stats, 5 MB at eight ranks) and gathered
     // straight away, the ghost rows of theta follow (every rank issues the two RCCL operations in this order), while
     // k_scan (without the statistics), k_prep and k_wind -- which need neither -- run on the caller's stream: the
-    // round trip of the all-gather is covered by them instead of starting only after k_scan and k_prep
-    // (measured, one-rank communicator: 61 -> see DESIGN.md 5).
-    HIPCHK(c, hipEventRecord(c->ev_fork, st));
-    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    // round trip of the all-gather is covered by them instead of starting only after k_scan and k_prep.
+    hipError_t he = hipEventRecord(c->ev_fork, st);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0);
+    if (he != hipSuccess) { c->gathered = saved_g; c->ngathered = saved_n; return hipfail(c, he, "band step fork"); }
+    rc = SB_OK;
     if (!reuse) {
-        if ((rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream))) return rc;
-        c->rep_launches += 2;
-        if ((rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream))) return rc;
+        rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream);
+        if (!rc) { c->rep_launches += 2; rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream); }
     }
-    if ((rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
-    const Moments *saved_g = c->gathered;
-    const int saved_n = c->ngathered;
-    c->gathered = (const Moments *)gath;
-    c->ngathered = c->nranks;
-    rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
-                               thc, sb_con, tun, (void *)st, 1);
-    if (!rc) {
-        hipError_t e = hipStreamWaitEvent(st, c->ev_join, 0);
-        if (e != hipSuccess) rc = hipfail(c, e, "hipStreamWaitEvent");
-    }
+    if (!rc) rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream);
+    // (whatever happened on the way: the second stream is joined into the caller's again)
+    he = hipEventRecord(c->ev_join, c->aux_stream);
+    if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
+                                        thc, sb_con, tun, (void *)st, 1);
+    if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
+    if (he != hipSuccess && !rc) rc = hipfail(c, he, "band step join");
     if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma,
                                         ws, wd, thc, sb_con, tun, (void *)st, 2);
     c->gathered = saved_g;
@@ -590,6 +589,7 @@ int stream_begin(sb_ctx *c, int nlons, int nlats, const T *z, const T *sd, const
     if (!z || !sd || !cdist || !ws || !wd || !thc) return fail(c, SB_ERR_ARG, "null array pointer");
     DiagStream &d = c->ds;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stats_valid = false;                 // a new std field arrives in the same device buffer
     const size_t n2 = (size_t)nlons * nlats, b2 = n2 * sizeof(T);
     for (DevBuf *b : {&d.z, &d.sd, &d.cdist, &d.ws, &d.wd, &d.thc, &d.theta, &d.v, &d.u})
         if ((rc = ensure(c, *b, b2))) return rc;
@@ -718,6 +718,7 @@ int sigmoid_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->stats_valid = false;                 // the shared scalars now belong to `ary`, not to a diag call's sigma
     HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, (T *)c->stats, nullptr, st));
     HIPCHK(c, sb_launch_sigmoid_apply<T>(ary, sm, (size_t)nx * ny, (const T *)c->stats, st));
     return SB_OK;
@@ -1029,13 +1030,6 @@ int sb_set_search_radius_hint(sb_ctx *c, int radius) {
     return SB_OK;
 }
 
-int sb_set_tile_rows(sb_ctx *c, int rows) {
-    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    if (rows != 0 && rows != 32 && rows != 48 && rows != 64) return fail(c, SB_ERR_ARG, "tile rows must be 0, 32, 48 or 64");
-    c->tile_rows = rows;
-    return SB_OK;
-}
-
 #ifdef SB_STAMPS
 // diagnostic build only: the per-workgroup clock sums of the last k_thc3 launch
 int sb_debug_stamps(sb_ctx *c, long long *host, int nwg) {
@@ -1045,19 +1039,6 @@ int sb_debug_stamps(sb_ctx *c, long long *host, int nwg) {
     return SB_OK;
 }
 #endif
-
-int sb_set_thc_threads(sb_ctx *c, int threads) {
-    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    if (threads != 0 && threads != 512 && threads != 1024) return fail(c, SB_ERR_ARG, "contrast-kernel workgroups have 512 or 1024 threads");
-    c->thc_nt = threads ? threads : 1024;
-    return SB_OK;
-}
-
-int sb_set_thc_prefetch(sb_ctx *c, int on) {
-    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    c->thc_prefetch = on ? 1 : 0;
-    return SB_OK;
-}
 
 int sb_last_counters(sb_ctx *c, long long counters[4]) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
@@ -1275,6 +1256,8 @@ int sb_comm_init(sb_ctx *c, const unsigned char id[128], int rank, int nranks) {
 int sb_comm_finalize(sb_ctx *c) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     if (c->comm) {
+        // every RCCL operation of a band step is enqueued on the communication stream: nothing may be in flight
+        if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
         (void)hipStreamSynchronize(c->stream);
         NCCLCHK(c, g_rccl.CommDestroy((ncclComm_t)c->comm));
     }
@@ -1414,12 +1397,6 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
     }
     NCCLCHK(c, g_rccl.AllGather(mine5, gathered, 5, ncclDouble, (ncclComm_t)c->comm, st));
     c->rep_rccl += 1;
-    return SB_OK;
-}
-
-int sb_set_overlap(sb_ctx *c, int on) {
-    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    c->overlap = on ? 1 : 0;
     return SB_OK;
 }
 

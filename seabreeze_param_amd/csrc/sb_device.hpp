@@ -261,6 +261,10 @@ struct DiagJob {
     const T *stats;                 // [0]=std  [1]=r  (sigmoid scalars)
     int thc_ty, thc_ntx, thc_nty;   // contrast-kernel tile rows and tile-grid shape
     int thc_txs;                    // log2 of the tile width (5: 32 longitudes)
+    int tile_sx, tile_sy, tile_off; // flag of tile (column tx, row ty) = tile_nnmax[tx * tile_sx + ty * tile_sy + tile_off]:
+                                    //   row-major for the tile kernel; strip-major with a virtual block above and below
+                                    //   every strip for the strip kernel (sb_strip_kernel.hip)
+    int strip;                      // 1: the strip kernel runs the contrast (LDS halo <= 16)
     int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius
     int *ticket;                    // spare device word (zeroed by k_scan)
     // lists k_prep compacts between k_scan and the kernels that consume them

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 hi = hi > 64 ? 64 : hi;
                 if (lane <= (64 >> txs) && lo < hi) {
                     const uint64_t m = (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
-                    if (wb & m) job.tile_nnmax[(yi / job.thc_ty) * job.thc_ntx + tA + lane] = 1;   // benign duplicates
+                    if (wb & m) job.tile_nnmax[(tA + lane) * job.tile_sx + (yi / job.thc_ty) * job.tile_sy + job.tile_off] = 1;   // benign duplicates
                 }
             }
             if (interior && yi < g.rows && !band) {
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(PREP_NT) void k_prep(DiagJob<T> job, const Moments 
         return;
     }
     if (blockIdx.x == 1) {
+        if (job.strip) return;                       // the strip kernel ranks the flags itself
         const int ntiles = job.thc_ntx * job.thc_nty;
         int total;
         if (ntiles <= PREP_MAXCH * PREP_NT) {
@@ -574,104 +575,6 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
 }
 
 // ------------------------------------------------------------------------------------
-// k_walk (overlap mode): k_wind's memory half only -- the level search down the p column and the loads of u, v at
-// that level -- with a register footprint small enough (launch bounds: 8 workgroups per CU) for its waves to live on
-// the registers k_thc3 leaves free.  It leaves u, v of the chosen level in nws / nwd; k_final turns them into speed
-// and direction.   ref: generic/sea_breeze_diag.f90:223 (or the UM walk, UM/...:265-274)
-// ------------------------------------------------------------------------------------
-template <typename T, int UN>
-__global__ __launch_bounds__(WIND_NT, 8) void k_walk(DiagJob<T> job) {
-    const Geo g = job.g;
-    const int lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * WIND_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * WIND_NT) job.next_flags[i] = 0;
-    const int cnt = lane < SB_SEG_PARTS ? job.seg_count[lane] : 0;
-    const int incl = sb_wave_scan_add(cnt);
-    const int total = __builtin_amdgcn_readlane(incl, SB_SEG_PARTS - 1);
-    const int nwaves = gridDim.x * (WIND_NT / SB_WAVE);
-    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6));
-    const size_t pl = (size_t)g.nx * g.ny;
-    const int nz = job.nz;
-    for (int e = gw; e < total; e += nwaves) {
-        const uint64_t hit = __ballot(lane < SB_SEG_PARTS && e < incl);
-        const int part = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
-        const int base = __shfl(incl, part) - __shfl(cnt, part);
-        const SbSegEntry cur = job.seg_list[(size_t)part * job.seg_cap + (e - base)];
-        if (!((cur.word >> lane) & 1ull)) continue;
-        const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
-        const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
-        const size_t o = (size_t)y * g.nx + x;
-        const T *pc = job.p + o;
-        int lev = 0;
-        if (job.level_rule == 0) {
-            T best = T(0);
-            for (int k0 = 0; k0 < nz; k0 += UN) {
-                T d[UN];
-#pragma unroll
-                for (int q = 0; q < UN; ++q) d[q] = sb_ld<T, true>(pc + (size_t)(k0 + q < nz ? k0 + q : nz - 1) * pl);
-#pragma unroll
-                for (int q = 0; q < UN; ++q) {
-                    const int k = k0 + q;
-                    const T a = fabs(d[q] - job.target_plev);
-                    if (k == 0) best = a;
-                    else if (k < nz && a < best) { best = a; lev = k; }
-                }
-            }
-        } else {
-            T diff = T(1000000.);
-            bool done = false;
-            for (int k0 = 0; k0 < nz && !done; k0 += UN) {
-                T d[UN];
-#pragma unroll
-                for (int q = 0; q < UN; ++q) d[q] = sb_ld<T, true>(pc + (size_t)(k0 + q < nz ? k0 + q : nz - 1) * pl);
-#pragma unroll
-                for (int q = 0; q < UN; ++q) {
-                    const int k = k0 + q;
-                    const T a = fabs(d[q] - job.target_plev);
-                    if (!done && k < nz) {
-                        if (a <= diff) { lev = k; diff = a; }
-                        else done = true;
-                    }
-                }
-            }
-        }
-        job.nws[o] = job.u[(size_t)lev * pl + o];
-        job.nwd[o] = job.v[(size_t)lev * pl + o];
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_final (overlap mode): wind speed and direction from the u, v k_walk left in nws / nwd (ref: generic/...:225-227),
-// then thresholds, scaling and state update of every band cell with this call's contrast (k_thc3 left it in thc)
-// (ref :235-266).
-// Same list-driven shape as k_wind: a wave per segment that holds band cells.
-// ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(WIND_NT) void k_final(DiagJob<T> job) {
-    const Geo g = job.g;
-    const int lane = threadIdx.x & 63;
-    const int cnt = lane < SB_SEG_PARTS ? job.seg_count[lane] : 0;
-    const int incl = sb_wave_scan_add(cnt);
-    const int total = __builtin_amdgcn_readlane(incl, SB_SEG_PARTS - 1);
-    const int nwaves = gridDim.x * (WIND_NT / SB_WAVE);
-    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6));
-    for (int e = gw; e < total; e += nwaves) {
-        const uint64_t hit = __ballot(lane < SB_SEG_PARTS && e < incl);
-        const int part = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
-        const int base = __shfl(incl, part) - __shfl(cnt, part);
-        const SbSegEntry cur = job.seg_list[(size_t)part * job.seg_cap + (e - base)];
-        if (!((cur.word >> lane) & 1ull)) continue;
-        const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
-        const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
-        const size_t o = (size_t)y * g.nx + x;
-        SbCellState<T> cs = sb_trigger_load<T>(job, o);
-        const T uu = cs.n_ws, vv = cs.n_wd;                      // k_walk left u, v of the chosen level there
-        cs.n_ws = sqrt(uu * uu + vv * vv);                        // ref :225
-        cs.n_wd = atan2(-uu, -vv) * T(57.2957);                   // ref :227, rad2deg (sic) :128
-        sb_trigger_update<T, false>(job, o, job.thc[o], cs);
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -717,6 +620,12 @@ static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
 #define SB_EV_BEGIN(k) do { if (ev) { (void)hipEventRecord(ev[2 * (k)], st); *lc.prof_mask |= 1u << (k); } } while (0)
 #define SB_EV_END(k)   do { if (ev) (void)hipEventRecord(ev[2 * (k) + 1], st); } while (0)
 
+// the contrast kernel for this job: marching strips (LDS halo 16) or LDS tiles (halos of 24 and 32 cells)
+template <typename T>
+static hipError_t launch_contrast(const DiagJob<T> &job, int H, int ncu, hipStream_t st) {
+    return job.strip ? sb_launch_strip<T>(job, ncu, st) : sb_launch_thc<T>(job, H, ncu, st);
+}
+
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     const Geo &g = job.g;
@@ -733,48 +642,21 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     if (nblk > lc.ncu) nblk = lc.ncu;                            // one 1024-thread workgroup per CU, two trips of loads in flight
     const dim3 pg(2 + SB_SEG_PARTS), pb(PREP_NT);
     // Single-domain calls run the contrast first and let k_wind apply the thresholds and the state update
-    // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there k_thc3
-    // applies them.
+    // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there the contrast
+    // kernel applies them.
     if (job.wind_final && ph1 && ph2) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
-        const int thc_threads = (H <= 16 && lc.thc_nt == 1024) ? 1024 : 512;
-        if (job.t0_fly && lc.overlap && job.nws && job.nwd) {
-            // k_prep, then k_thc3 (enqueued first, so that its one workgroup per CU is resident when k_wind's
-            // fill the registers it leaves) and k_wind side by side, then the update
-            SB_EV_BEGIN(SB_PROF_PREP);
-            hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, reuse ? 0 : nblk, (T *)lc.stats, (Moments *)nullptr);
-            SB_EV_END(SB_PROF_PREP);
-            if ((e = hipEventRecord(lc.ev_fork, st)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(lc.aux, lc.ev_fork, 0)) != hipSuccess) return e;
-            DiagJob<T> tj = job;
-            tj.no_prefetch = 1;
-            SB_EV_BEGIN(SB_PROF_THC);
-            if ((e = sb_launch_thc<T>(tj, H, lc.ncu, 512, st)) != hipSuccess) return e;   // 8 waves x 160 registers
-            DiagJob<T> wj = job;
-            wj.wind_final = 0;
-            // 2 x 160 registers of k_thc3 leave 192 per SIMD lane: four k_walk waves of 40; two more workgroups per CU
-            // queue up for the CUs whose k_thc3 workgroup ends early
-            hipLaunchKernelGGL((k_walk<T, SB_WIND_UN>), dim3(lc.ncu * 6), dim3(WIND_NT), 0, lc.aux, wj);
-            if ((e = hipEventRecord(lc.ev_join, lc.aux)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(st, lc.ev_join, 0)) != hipSuccess) return e;
-            SB_EV_END(SB_PROF_THC);                              // k_thc3 and k_wind together
-            SB_EV_BEGIN(SB_PROF_WIND);
-            hipLaunchKernelGGL(k_final<T>, dim3(lc.ncu * 8), dim3(WIND_NT), 0, st, job);
-            SB_EV_END(SB_PROF_WIND);                             // k_final
-            if (lc.launches) *lc.launches += 5;
-            return hipGetLastError();
-        }
-        // host-model flavour: k_thc3 does k_prep's work itself (one dependent launch less on the critical path)
-        if (job.t0_fly && !lc.no_fold && sb_thc_can_fold(job.thc_ntx * job.thc_nty, nblk, lc.ncu, thc_threads)) {
+        // host-model flavour: the strip kernel does k_prep's work itself (one dependent launch less on the critical path)
+        if (job.strip && job.t0_fly && !lc.no_fold && nblk <= 1024) {
             DiagJob<T> fj = job;
             fj.fold = 1;
             fj.fold_partials = lc.partials;
             fj.fold_nparts = reuse ? 0 : nblk;
             fj.stats_out = (T *)lc.stats;
             SB_EV_BEGIN(SB_PROF_THC);
-            if ((e = sb_launch_thc<T>(fj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+            if ((e = launch_contrast<T>(fj, H, lc.ncu, st)) != hipSuccess) return e;
             SB_EV_END(SB_PROF_THC);
             SB_EV_BEGIN(SB_PROF_WIND);
             launch_wind<T>(job, lc.ncu, st);
@@ -793,7 +675,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             ++nl;
         }
         SB_EV_BEGIN(SB_PROF_THC);
-        if ((e = sb_launch_thc<T>(job, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+        if ((e = launch_contrast<T>(job, H, lc.ncu, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
         SB_EV_BEGIN(SB_PROF_WIND);
         launch_wind<T>(job, lc.ncu, st);
@@ -825,7 +707,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     if (ph2) {
         DiagJob<T> pj = job;
         if (gathered && !reuse) {
-            if (job.t0_fly) {                                    // k_thc3 merges the gathered moments in its prologue
+            if (job.t0_fly) {                                    // the contrast kernel merges the gathered moments in its prologue
                 pj.gath = lc.gathered;
                 pj.ngath = lc.ngathered;
                 pj.stats_out = (T *)lc.stats;
@@ -841,7 +723,7 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             ++nl;
         }
         SB_EV_BEGIN(SB_PROF_THC);
-        if ((e = sb_launch_thc<T>(pj, H, lc.ncu, lc.thc_nt, st)) != hipSuccess) return e;
+        if ((e = launch_contrast<T>(pj, H, lc.ncu, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
         ++nl;
     }

@@ -28,17 +28,10 @@ struct SbLaunchCtx {
     int ngathered;
     Moments *moments_out;           // band step: k_scan's own moments go here (k_prep) ...
     hipEvent_t moments_event;       // ... and this event is recorded behind them, or nullptr
-    int ncu;                        // compute units (k_scan / k_thc3 run one workgroup per CU)
-    int thc_nt;                     // threads of a k_thc3 workgroup: 512 or 1024
+    int ncu;                        // compute units (k_scan and the contrast kernel run one workgroup per CU)
     int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
     bool reuse_stats;               // the sigmoid scalars in `stats` stand (static sigma): no moments, no merge
-    // overlap mode (single-domain host-model calls): k_thc3 (VALU/LDS-bound, without its register prefetch) on the
-    // caller's stream and k_walk (k_wind's HBM-bound half: level search, u, v) on aux run side by side; k_final
-    // derives the wind and applies the update.
-    bool overlap;
-    hipStream_t aux;
-    hipEvent_t ev_fork, ev_join;
     bool no_fold;                   // keep k_prep as a kernel of its own (sb_set_fold(ctx, 0): measurement and tests)
     int *launches;                  // += kernels enqueued by the call, or nullptr
 };
@@ -50,13 +43,17 @@ template <typename T>
 hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats, hipStream_t st);
 template <typename T>
 hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc);
-// tile size of the contrast kernel that will run for an LDS halo of H cells
-void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty);
-// can k_thc3 take over k_prep's work (job.fold) for this many tiles, partial moments and workgroups?
-bool sb_thc_can_fold(int ntiles, int nparts, int nblocks, int threads);
-// the contrast kernel: reads the list of active tiles and the sigmoid scalars k_prep left
+// tile size of the tile contrast kernel (k_thc3) for an LDS halo of H = 24 or 32 cells
+void sb_thc_tile_shape(int H, int *tx, int *ty);
+// the tile contrast kernel (halos of 24 and 32 cells): reads the list of active tiles and the sigmoid scalars k_prep left
 template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStream_t st);   // nt: 512 or 1024 threads
+hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st);
+
+// the marching-strip contrast kernel (sb_strip_kernel.hip): LDS halo of 16 cells, ranks k_scan's flags itself
+template <typename T>
+hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st);
+// its block grid (strips x 16-row blocks) for nx x rows interior cells; false: the grid is too large for it
+bool sb_strip_shape(int nx, int rows, int *ntx, int *nty);
 
 // theta <- theta - (gmma*z)*sigmoid(sigma) over n cells, with the scalars the last diag call left in `stats`
 template <typename T>

@@ -1,0 +1,615 @@
+// sb_strip_kernel.hip -- thermal heating contrast (the expanding-window land/sea mean difference of t0)
+// on gfx950 for search radii up to 16 cells: marching strips.
+// ref: generic/sea_breeze_diag.f90:166-167 (t0), :188-216 (window search and contrast),
+//      python_wrapper/seabreezediag/seabreeze_diag_python.f90:187-221
+//
+// The reference re-sums a (2nn+1)^2 window from scratch at every radius nn until it holds both classes; only the
+// last square matters, and "holds both classes" is monotone in nn.  So summed-area tables (all cells, land-side
+// cells, land-side count) answer any square with four reads per table and a bisection on the count table finds nn.
+//
+// Layout.  The grid is cut into strips of 32 owned longitudes; with the halo of 16 cells either side a staged row
+// is exactly one 64-lane wave (lane = column).  A strip is cut into blocks of 16 rows (one row per wave of the
+// 1024-thread workgroup).  k_scan raises a flag per (strip, block) that holds a coastal-band cell; the flags are laid
+// out strip-major with one virtual block above and below every strip, so that "the blocks before and after an
+// active block" is plain bit arithmetic on a bit plane.  Every workgroup takes an equal share of the active blocks
+// in that order -- consecutive blocks down a strip -- and MARCHES: it stages block after block into a ring of 128
+// table rows in LDS, queries the band cells of block j once block j+1 is in the ring, and never stages a row twice
+// inside a run (where the tile kernel re-staged a 16-row halo above and below every 48-row tile).
+//
+// Arithmetic.  t0 is turned into 64-bit fixed point (2^-40 K: below the spacing of doubles near 300 K by 16, so
+// window sums are EXACT integer sums of values rounded once) -- the prefix sums are then integer adds, which
+// (a) wrap harmlessly, so the tables need no per-tile offset and the ring never has to be re-based,
+// (b) take two full-rate DPP instructions per scan step (v_add_co / v_addc with the lane shift fused), where the
+//     fp64 scan took two DPP moves and a half-rate v_add_f64,
+// (c) make the result independent of how the grid is cut into strips, blocks, bands or GPUs, bit for bit.
+//
+// Per block (one barrier):
+//   S1  every wave: its row's inputs (prefetched three blocks ahead into registers) -> t0 -> fixed point ->
+//       prefix along longitude of {all, land-side, land-side count} -> ring row (not yet summed along latitude)
+//   --- barrier (LDS only: the prefetched global loads stay in flight) ---
+//   S2  waves 0-2: one table each, prefix along latitude of the 16 new rows (running column totals in registers)
+//       waves 3-10: band cells of the block staged two steps ago: bisection for the radius, contrast, result
+//       (the other waves go straight on to S1 of the next block)
+#include "sb_thc_common.hpp"
+
+#define STRIP_H 16                // halo of the tables = largest radius answered from LDS
+#define STRIP_W 64                // staged columns = lanes
+#define STRIP_SW (STRIP_W - 2 * STRIP_H)
+#define STRIP_C 16                // rows per block = waves per workgroup
+#define STRIP_NT 1024
+#define STRIP_RING 128            // ring rows (8 blocks): a query of block j reads rows of blocks j-2 .. j+1 while
+                                  // block j+3 may already be written
+#define STRIP_P (STRIP_W + 1)     // table pitch: column 0 is the zero column
+#define STRIP_MAXW 1024           // 64-bit words of the position plane a workgroup can hold (65,535 positions)
+#define STRIP_SCHED 512           // staged blocks of one round of a workgroup
+#define STRIP_ROUND 120           // active blocks of one round (at most 3 x 120 staged blocks + 120 drain + 3 warm-up steps)
+#define STRIP_FB 40               // fractional bits of the fixed-point t0
+#define STRIP_DEPTH 3             // blocks of inputs in flight per wave
+
+typedef unsigned long long u64;
+
+#ifdef SB_STAMPS
+#define SB_T(i) do { const long long t_now = clock64(); acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define SB_T(i) do { } while (0)
+#endif
+
+// t0 (K) -> fixed point.  fma rounds x * 2^40 + 1.5 * 2^52 to an integer held in the mantissa (|x| <= 1024).
+__device__ __forceinline__ u64 sb_to_fixed(double x) {
+    x = fmin(fmax(x, -1024.0), 1024.0);
+    const double y = __builtin_fma(x, 0x1p40, 0x1.8p52);
+    return (u64)(__double_as_longlong(y) - __double_as_longlong(0x1.8p52));
+}
+
+// inclusive prefix sums over the 64 lanes of a wave of two 64-bit integers at once: per step and value one
+// v_add_co_u32 + one v_addc_co_u32, the lane shift fused into the add (DPP).  The two chains alternate, so a value
+// written by one step is read by the next four instructions later (a DPP read needs two wait states after a VALU
+// write; hipcc pads nothing inside an asm statement -- hence also the leading s_nop).  Needs all 64 lanes active.
+__device__ __forceinline__ void sb_scan2_u64(u64 &a, u64 &b) {
+    unsigned al = (unsigned)a, ah = (unsigned)(a >> 32), bl = (unsigned)b, bh = (unsigned)(b >> 32);
+#define SB_SCAN_STEP(ctl)                                          \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctl "\n\t"               \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctl "\n\t"         \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " ctl "\n\t"               \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 SB_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 SB_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh)::"vcc");
+#undef SB_SCAN_STEP
+    a = ((u64)ah << 32) | al;
+    b = ((u64)bh << 32) | bl;
+}
+
+__device__ __forceinline__ u64 sb_uniform64(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// the position of rank r among the set bits of the plane (bit b of word k = position 64 k + b), or -1; popcounts, a
+// wave scan per 64 words and ballots; wave-uniform, every wave computes the same
+__device__ __forceinline__ int strip_pick(const u64 *s_bits, int nwords, int r, int lane) {
+    int pos = -1, run = 0;
+    for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
+        const u64 w = (k0 + lane < nwords) ? s_bits[k0 + lane] : 0ull;
+        const int pc = __popcll(w);
+        const int incl = sb_wave_scan_add(pc);
+        const int before = run + incl - pc;
+        run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
+        const u64 hit = __ballot(before <= r && r < before + pc);
+        if (hit) {                                               // wave-uniform; one lane of one chunk
+            const int src = __ffsll((unsigned long long)hit) - 1;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, src);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), src);
+            const u64 word = ((u64)hi << 32) | lo;
+            const int n = r - __builtin_amdgcn_readlane(before, src);
+            const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
+            const u64 sel = __ballot(me);
+            pos = (k0 + src) * 64 + __ffsll((unsigned long long)sel) - 1;
+            break;
+        }
+    }
+    return pos;
+}
+
+// what a lane holds of one staged row between the issue of its loads and S1
+template <typename T, bool FLY>
+struct StripRegs {
+    T th;                          // theta (FLY) or t0
+    T zz, sg;                      // z, sigma (FLY only)
+    uint32_t lw;                   // the 32-bit half of the land-side word that holds the cell
+    int sh;                        // the cell's bit in lw; -1: no such cell
+};
+
+// schedule entry of a staged block: position | flags
+#define SCH_Q2 (1u << 16)          // the block two positions up is active: its band cells are queried in this step's S2
+#define SCH_RESTART (1u << 17)     // the block before is not staged: the tables start afresh here
+#define SCH_DRAIN (1u << 18)       // no block: the step behind the last block of a run, in which ...
+#define SCH_Q1 (1u << 19)          // ... the block one position up (the run's last active one) is queried
+#define SCH_IDLE (1u << 20)        // nothing but the loads of the block three steps on (warm-up and padding steps)
+#define SCH_NONE 0xffffffffu
+
+template <typename T, bool FLY, bool WF>     // FLY: t0 from theta, z, sigma while staging; WF: k_wind applies the update
+__global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats, int G, DiagJob<T> job) {
+    constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
+    static_assert(NWV == C, "one staged row per wave");
+    __shared__ u64 sA[STRIP_RING * P];                 // prefix sums of t0 (fixed point), every cell
+    __shared__ u64 sL[STRIP_RING * P];                 // ... land-side cells
+    __shared__ unsigned short sC[STRIP_RING * P];      // ... land-side count (modulo 2^16: a window holds < 2^16 cells)
+    __shared__ u64 s_land[STRIP_RING];                 // land-side bits of every ring row
+    __shared__ u64 s_bits[STRIP_MAXW];                 // the active blocks as a bit plane
+    __shared__ unsigned s_sched[STRIP_SCHED];          // staged blocks of the round: position | flags
+    __shared__ unsigned s_sjp[STRIP_SCHED];            // ... strip << 16 | block within the padded strip
+    __shared__ Moments s_wpart[NWV];
+    __shared__ int s_scan[NWV];
+    __shared__ int s_misc[4];
+    __shared__ T s_sdr[2];
+    static_assert(sizeof(u64) * (2 * STRIP_RING * P + STRIP_RING + STRIP_MAXW) + 2 * STRIP_RING * P + 8 * STRIP_SCHED +
+                          sizeof(Moments) * NWV + 4 * NWV + 16 + 16 <= 160 * 1024,
+                  "k_strip: LDS of one workgroup");
+
+    const Geo g = job.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npad = job.thc_nty + 2;                  // blocks of a strip incl. the virtual ones above and below
+    const int npos = job.thc_ntx * npad;
+
+#ifdef SB_STAMPS
+    long long acc[SB_NSTAMP], t_last = clock64();
+    const long long w_begin = wall_clock64();
+    for (int i = 0; i < SB_NSTAMP; ++i) acc[i] = 0;
+#endif
+    // ---- prologue 1: the flags k_scan raised, 1024 at a time, as a bit plane (word c NWV + wv = ballot of chunk c) ----
+    T sd = T(0), rr = T(0);
+    Moments pm = moments_empty();
+    double shift_c = 0.0;
+    const bool fold_stats = job.fold && job.fold_nparts > 0;
+    if (fold_stats) {
+        if (tid < job.fold_nparts) pm = job.fold_partials[tid];
+        shift_c = (double)job.sigma[(size_t)g.h * g.nxh + g.h];
+    } else if (FLY && job.ngath > 0) {
+        // band step: the first wave merges the moments gathered from all ranks in rank order (one tree on every
+        // workgroup of every rank: identical scalars everywhere); workgroup 0 publishes them
+        if (wv == 0) {
+            Moments m = moments_empty();
+            for (int b = lane; b < job.ngath; b += SB_WAVE) m = moments_merge(m, job.gath[b]);
+            m = wave_merge(m);
+            if (lane == 0) {
+                T st4[4];
+                sigmoid_scalars<T>(m, st4);
+                s_sdr[0] = st4[0]; s_sdr[1] = st4[1];
+                if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
+            }
+        }
+    } else if (FLY) { sd = stats[0]; rr = stats[1]; }
+    const int nch = (npos + STRIP_NT - 1) / STRIP_NT;            // <= 64 (host)
+    {
+        u64 mine = 0;
+        for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
+            int f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = (base + j) * STRIP_NT + tid;
+                f[j] = job.tile_nnmax[i < npos ? i : npos - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = (base + j) * STRIP_NT + tid;
+                mine |= (i < npos && f[j] != 0) ? 1ull << (base + j) : 0ull;
+            }
+        }
+        for (int c = 0; c < nch; ++c) {
+            const u64 b = __ballot((mine >> c) & 1ull);
+            if (lane == 0) s_bits[c * NWV + wv] = b;
+        }
+    }
+    // the zero column of the three tables (never written again) while the flags travel
+    for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
+    if (fold_stats) wave_total_shifted_store(pm, s_wpart);
+    __syncthreads();
+    if (fold_stats) {
+        // k_scan's shifted sums added up in k_prep's order; every thread derives the scalars itself (identical bits)
+        const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
+        T st4[4];
+        sigmoid_scalars<T>(m, st4);
+        sd = st4[0]; rr = st4[1];
+        if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
+    } else if (FLY && job.ngath > 0) { sd = s_sdr[0]; rr = s_sdr[1]; }
+    const int nwords = nch * NWV;
+    // this workgroup's share of the active blocks: ranks [r0, r1) in strip-major order
+    int nact = 0;
+    for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) nact += (k0 + lane < nwords) ? __popcll(s_bits[k0 + lane]) : 0;
+    nact = sb_wave_scan_add(nact);
+    nact = __builtin_amdgcn_readlane(nact, SB_WAVE - 1);
+    const int r_begin = (int)(((long long)blockIdx.x * nact) / G), r_end = (int)(((long long)(blockIdx.x + 1) * nact) / G);
+
+    const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
+    ThcBufs<FLY> B;
+    B.th = sb_make_rsrc(FLY ? (const void *)job.theta : (const void *)job.t0, fbytes);
+    B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.t0, fbytes);
+    B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.t0, fbytes);
+    B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
+    const bool fastx = g.nx > W + 2;                   // one conditional add wraps every column of a staged row
+    const bool limited = g.bnd == BND_HALO;
+
+    // loads of row wv of the block at position pos
+    // (always four loads, also behind the end of the schedule and for a drain step, from clamped addresses: the
+    // compiler counts the loads in flight per program point, and a path without them would make it drain the queue)
+    auto issue = [&](StripRegs<T, FLY> &R, unsigned sj) __attribute__((always_inline)) {
+        const int strip = (int)(sj >> 16), jp = (int)(sj & 0xffffu);
+        const int ys = (jp - 1) * C + wv;               // interior row (may lie outside the grid: clamped or absent)
+        const int xs = strip * SW - H + lane;
+        bool ok = true;
+        int Xc = 0;
+        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = Xc >= 0 && Xc < g.nxh; }
+        else if (fastx) {
+            if (g.bnd == BND_WRAPPER) {
+                int m = xs + 1;
+                m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
+                Xc = (m < 1 ? 1 : m) - 1;
+            } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
+        } else {
+            int Yd;
+            sb_map_cell(g, xs, 0, Xc, Yd);
+        }
+        int Yr;
+        bool rowok = true;
+        if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
+        else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
+        const unsigned xc = ok ? (unsigned)Xc : 0u;     // every load is unconditional, from a clamped address
+        const unsigned colb = xc * (unsigned)sizeof(T), clsb = (xc >> 5) * 4u;
+#if defined(STRIP_EXP) && (STRIP_EXP & 1)
+        Yr = wv;                                         // experiment: every block reads the same 16 rows (cache hits)
+#endif
+        const unsigned rowb = (unsigned)Yr * (unsigned)g.nxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
+        R.th = sb_buf_ld<T>(B.th, colb, rowb);
+        if constexpr (FLY) { R.zz = sb_buf_ld<T>(B.zz, colb, rowb); R.sg = sb_buf_ld<T>(B.sg, colb, rowb); }
+        R.lw = __builtin_amdgcn_raw_buffer_load_b32(B.cls, clsb, wordb, 0);
+        R.sh = (ok && rowok) ? (int)(xc & 31u) : -1;
+    };
+
+    // running column totals of the table this wave sums along latitude (waves 0, 1: 64 bit; wave 2: the count)
+    u64 carry = 0;
+
+    // S1: the row's registers -> ring row (prefix along longitude only)
+    auto stage = [&](StripRegs<T, FLY> &R, unsigned ent, int jp) __attribute__((always_inline)) {
+        const bool ok = R.sh >= 0;
+        const bool land = ok && ((R.lw >> (R.sh & 31)) & 1u);
+        T t0v = R.th;
+        if constexpr (FLY) {
+            // the sigmoid only where a lane of the wave stands on land (z == 0 -> t0 = theta exactly)   ref :166-167
+#if !(defined(STRIP_EXP) && (STRIP_EXP & 2))
+            if (__ballot(ok && R.zz != T(0)) != 0) t0v = sb_t0<T>(R.th, R.zz, R.sg, sd, rr);
+#else
+            t0v = R.th + R.zz * R.sg;                    // experiment: no sigmoid
+#endif
+        }
+        u64 qa = ok ? sb_to_fixed((double)t0v) : 0ull;
+        u64 ql = land ? qa : 0ull;
+        const u64 lm = __ballot(land);
+        sb_scan2_u64(qa, ql);
+        const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u)) + (land ? 1u : 0u);
+        const int slot = (jp * C + wv) & (STRIP_RING - 1);
+        const int o = slot * P + lane + 1;
+        sA[o] = qa;
+        sL[o] = ql;
+        sC[o] = (unsigned short)cnt;
+        if (lane == 0) s_land[slot] = lm;
+        if (ent & SCH_RESTART) {
+            // the tables start afresh: the row above the first one reads as zero, the running totals start at zero
+            if (wv == NWV - 1) {
+                const int z = ((jp * C - 1) & (STRIP_RING - 1)) * P + lane + 1;
+                sA[z] = 0; sL[z] = 0; sC[z] = 0;
+            }
+            carry = 0;
+        }
+    };
+
+    // S2, waves 0-2: prefix along latitude of the 16 rows of the block at ring position jp
+    auto vertical = [&](int jp) __attribute__((always_inline)) {
+        if (wv < 2) {
+            u64 *tab = wv == 0 ? sA : sL;
+#pragma unroll
+            for (int h0 = 0; h0 < C; h0 += 8) {          // eight rows of reads in flight
+                u64 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tab[((jp * C + h0 + i) & (STRIP_RING - 1)) * P + lane + 1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { carry += v[i]; tab[((jp * C + h0 + i) & (STRIP_RING - 1)) * P + lane + 1] = carry; }
+            }
+        } else {
+            unsigned v[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) v[i] = sC[((jp * C + i) & (STRIP_RING - 1)) * P + lane + 1];
+            unsigned cc = (unsigned)carry;
+#pragma unroll
+            for (int i = 0; i < C; ++i) { cc += v[i]; sC[((jp * C + i) & (STRIP_RING - 1)) * P + lane + 1] = (unsigned short)cc; }
+            carry = cc;
+        }
+    };
+
+    // The band bits of the two rows this wave queries in block jp of `strip`, as SCALAR loads (constant address
+    // space: the plane is k_scan's, read-only here).  Scalar loads count in lgkmcnt, which the step's barrier waits
+    // for anyway; a vector load here would sit in the in-order vmcnt queue between the prefetched blocks, and the
+    // wait for it would drain every load issued before it.
+    struct BandWords { u64 a0, b0, a1, b1, c0, c1; int sh; };   // c: land-side word of the last longitude (f2py rule)
+    typedef const __attribute__((address_space(4))) u64 *cu64p;
+    auto band_issue = [&](int strip, int jp) __attribute__((always_inline)) -> BandWords {
+        const int k = min(max(wv - 3, 0), C / 2 - 1);
+        const int y0 = (jp - 1) * C + 2 * k;
+        const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
+        const int xa = strip * SW + g.h;                 // array column of the strip's first owned cell
+        const int wlo = xa >> 6, whi = min(wlo + 1, g.nw - 1);
+        cu64p bits = (cu64p)job.bandbits;
+        BandWords w;
+        w.a0 = bits[(size_t)(ya + g.h) * g.nw + wlo]; w.b0 = bits[(size_t)(ya + g.h) * g.nw + whi];
+        w.a1 = bits[(size_t)(yb + g.h) * g.nw + wlo]; w.b1 = bits[(size_t)(yb + g.h) * g.nw + whi];
+        w.sh = xa & 63;
+        w.c0 = w.c1 = 0;
+        if (g.bnd == BND_WRAPPER && strip == job.thc_ntx - 1) {  // uniform; the strip that owns longitude nx
+            cu64p cls = (cu64p)job.clsbits;
+            const int wl = (g.nx - 1 + g.h) >> 6;
+            w.c0 = cls[(size_t)(ya + g.h) * g.nw + wl]; w.c1 = cls[(size_t)(yb + g.h) * g.nw + wl];
+        }
+        return w;
+    };
+
+    // S2, waves 3-10: the band cells of two rows of the block at position qpos
+    auto query = [&](int qpos, int strip, int jp, const BandWords &bwd, bool qdo) __attribute__((always_inline)) {
+        const int lx = lane & (SW - 1), ly = 2 * min(max(wv - 3, 0), C / 2 - 1) + (lane >> 5);
+        const int x = strip * SW + lx, y = (jp - 1) * C + ly;
+        // (the four words are scalars: shift each by the lane's amount, then select -- a select between the words
+        // themselves makes the compiler index them in scratch memory)
+        const int bp = bwd.sh + lx;
+        const unsigned sa = (unsigned)(bp & 63);
+        const unsigned bit0 = (unsigned)((bp < 64 ? bwd.a0 >> sa : bwd.b0 >> sa) & 1ull);
+        const unsigned bit1 = (unsigned)((bp < 64 ? bwd.a1 >> sa : bwd.b1 >> sa) & 1ull);
+        const bool bit = ((lane >> 5) ? bit1 : bit0) != 0u;
+        const bool isband = qdo && x < g.nx && y >= 0 && y < g.rows && bit;
+        if (__ballot(isband) == 0) return;              // wave-uniform
+        const size_t o = (size_t)(isband ? y : 0) * g.nx + (isband ? x : 0);
+        SbCellState<T> cst = SbCellState<T>{T(0), T(0), T(0), T(0)};
+        if constexpr (!WF) { if (isband) cst = sb_trigger_load<T>(job, o); }
+        int lim = H;
+        if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
+        const int limc = max(lim, 1);
+        const int rho = jp * C + ly;                     // ring row of the cell
+        const int cx = lx + H + 1;                       // its table column
+        // land-side count of the square of radius rad: C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0),
+        // r0 = rho-rad-1, r1 = rho+rad, a0 = cx-rad-1, a1 = cx+rad
+        auto count = [&](int rad) __attribute__((always_inline)) {
+            const int r1 = ((rho + rad) & (STRIP_RING - 1)) * P, r0 = ((rho - rad - 1) & (STRIP_RING - 1)) * P;
+            const int a1 = cx + rad, a0 = cx - rad - 1;
+            return (int)(unsigned short)((unsigned)sC[r1 + a1] - (unsigned)sC[r0 + a1] - (unsigned)sC[r1 + a0] + (unsigned)sC[r0 + a0]);
+        };
+        // the widest square, then a branch-free bisection (1 + log2 H probes of 4 reads)
+        int nl = count(limc);
+        const bool got = nl > 0 && nl < (2 * limc + 1) * (2 * limc + 1);
+        const bool found = isband && lim >= 1 && got;
+        int lo = got ? 1 : limc, hi = limc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const int nlm = count(mid);
+            const bool act = lo < hi, okm = nlm > 0 && nlm < (2 * mid + 1) * (2 * mid + 1);
+            nl = (act && okm) ? nlm : nl;
+            hi = (act && okm) ? mid : hi;
+            lo = (act && !okm) ? mid + 1 : lo;
+        }
+        const int nn = hi, area = (2 * nn + 1) * (2 * nn + 1);
+        const int r1 = ((rho + nn) & (STRIP_RING - 1)) * P, r0 = ((rho - nn - 1) & (STRIP_RING - 1)) * P;
+        const int a1 = cx + nn, a0 = cx - nn - 1;
+        const u64 l11 = sL[r1 + a1], l01 = sL[r0 + a1], l10 = sL[r1 + a0], l00 = sL[r0 + a0];
+        const u64 q11 = sA[r1 + a1], q01 = sA[r0 + a1], q10 = sA[r1 + a0], q00 = sA[r0 + a0];
+        const u64 ownw = s_land[rho & (STRIP_RING - 1)];
+        const long long RL = (long long)((l11 - l01) - (l10 - l00));      // exact: the tables wrap, the window sum does not
+        const long long RA = (long long)((q11 - q01) - (q10 - q00));
+        // the two means by reciprocals of the (small, exact) counts: within an ulp of the quotients
+        const double ml = (double)RL * sb_inv((double)nl), ms = (double)(RA - RL) * sb_inv((double)(area - nl));
+        const T contrast = (T)((ml - ms) * 0x1p-40);
+        // the cell's own class: the table's centre, except that the f2py boundary rule maps the centre of the
+        // window at the last longitude to column 1   ref :182-186, seabreeze_diag_python.f90:202
+        // (there the cell's own land-side bit comes from the plane itself: scalar words, loaded with the band words)
+        bool own = (ownw >> (lx + H)) & 1ull;
+        if (g.bnd == BND_WRAPPER && x == g.nx - 1) {
+            const unsigned sl = (unsigned)((g.nx - 1 + g.h) & 63);
+            own = ((lane >> 5) ? (bwd.c1 >> sl) : (bwd.c0 >> sl)) & 1ull;
+        }
+        const T mul = own ? T(1) : T(-1);
+        int nnmax = 0;
+        if (found) {
+            nnmax = nn;
+            if constexpr (WF) job.thc[o] = mul * contrast;                   // ref :216; k_wind applies :235-266
+            else sb_trigger_update<T>(job, o, mul * contrast, cst);           // ref :216, :235-266
+        }
+        // cells whose window outgrows the tables (none on a grid whose distance field was made with a window of
+        // at most 15 cells): global-memory path
+        if (__ballot(isband && !found) != 0) {
+            if (isband && !found) {
+                int cap = g.nx + g.ny;
+                if (limited) cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
+                bool one_class;
+                int nng;
+                const T cg = contrast_global(job, x, y, cap, sd, rr, nng, one_class);
+                atomicAdd(&job.counters[0], 1);
+                if (one_class) atomicAdd(&job.counters[1], 1);
+                nnmax = nng;
+                const T mulg = sb_bit(job.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
+                if constexpr (WF) job.thc[o] = mulg * cg;
+                else sb_trigger_update<T>(job, o, mulg * cg, cst);
+            }
+        }
+        // per-block largest radius (diagnostic, read by sb_last_counters); the flag k_scan raised is 1
+        nnmax = sb_wave_max_to_last(nnmax);
+        if (lane == SB_WAVE - 1 && nnmax > 1) atomicMax(&job.tile_nnmax[qpos], nnmax);
+    };
+
+    SB_T(0);                                             // prologue
+    // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
+    for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
+        const int rb = min(ra + STRIP_ROUND, r_end);
+        const int p0 = strip_pick(s_bits, nwords, ra, lane), p1 = strip_pick(s_bits, nwords, rb - 1, lane);
+        if (p0 < 1 || p1 < p0) break;                    // (cannot happen: ranks below the count exist, position 0 is virtual)
+        // -- the schedule: staged positions in ascending order with their flags, by wave 0 --
+        // act = active blocks of this round; staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
+        const int kw0 = p0 >> 6, kw1 = p1 >> 6;
+        if (wv == 0) {
+            // (three warm-up steps lead the schedule: they stage nothing and only issue the loads of the first three
+            // blocks, so that every load of the loop is issued at the same three program points -- see `step`)
+            if (lane < STRIP_DEPTH) { s_sched[lane] = SCH_DRAIN | SCH_IDLE; s_sjp[lane] = 0; }
+            int n_out = STRIP_DEPTH;
+            for (int kb = kw0 - 1; kb <= kw1 + 1; kb += SB_WAVE) {
+                const int k = kb + lane;
+                u64 a[5];
+#pragma unroll
+                for (int d = 0; d < 5; ++d) {
+                    const int kk = k + d - 2;
+                    u64 w = (kk >= kw0 && kk <= kw1) ? s_bits[kk] : 0ull;
+                    if (kk == kw0) w &= ~0ull << (p0 & 63);
+                    if (kk == kw1) w &= ~0ull >> (63 - (p1 & 63));
+                    a[d] = w;
+                }
+                auto st_of = [&](u64 prev, u64 cur, u64 next) { return cur | (cur << 1) | (prev >> 63) | (cur >> 1) | (next << 63); };
+                const u64 s_prev = st_of(a[0], a[1], a[2]), s_cur = st_of(a[1], a[2], a[3]), s_next = st_of(a[2], a[3], a[4]);
+                u64 st = (k >= kw0 - 1 && k <= kw1 + 1 && k >= 0 && k < STRIP_MAXW) ? s_cur : 0ull;
+                const u64 q2 = (a[2] << 2) | (a[1] >> 62), q1 = (a[2] << 1) | (a[1] >> 63);
+                const u64 rs = st & ~((s_cur << 1) | (s_prev >> 63)), en = st & ~((s_cur >> 1) | (s_next << 63));
+                const int pc = __popcll(st) + __popcll(en);     // a drain step follows the last block of a run
+                const int incl = sb_wave_scan_add(pc);
+                int at = n_out + incl - pc;
+                n_out += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
+                while (st) {
+                    const int b = __ffsll((unsigned long long)st) - 1;
+                    st &= st - 1;
+                    const int pp = k * 64 + b, sp = pp / npad;
+                    const unsigned sjv = ((unsigned)sp << 16) | (unsigned)(pp - sp * npad);
+                    unsigned e = (unsigned)pp;
+                    e |= ((q2 >> b) & 1ull) ? SCH_Q2 : 0u;
+                    e |= ((rs >> b) & 1ull) ? SCH_RESTART : 0u;
+                    if (at < STRIP_SCHED) { s_sched[at] = e; s_sjp[at] = sjv; }
+                    ++at;
+                    if ((en >> b) & 1ull) {
+                        if (at < STRIP_SCHED) { s_sched[at] = (unsigned)pp | SCH_DRAIN | (((q1 >> b) & 1ull) ? SCH_Q1 : 0u); s_sjp[at] = sjv; }
+                        ++at;
+                    }
+                }
+            }
+            // (padded to a multiple of three with steps that do nothing: the loop below has no early exit -- with one,
+            // the compiler's count of the loads in flight collapses and it drains the queue every third step)
+            n_out = min(n_out, STRIP_SCHED - 2);
+            const int n_pad = (n_out + STRIP_DEPTH - 1) / STRIP_DEPTH * STRIP_DEPTH;
+            if (lane < n_pad - n_out) { s_sched[n_out + lane] = SCH_DRAIN | SCH_IDLE; s_sjp[n_out + lane] = 0; }
+            if (lane == 0) s_misc[0] = n_pad;
+        }
+        __syncthreads();
+        const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        // (behind the end: the last entry's position again, as a drain step without a query -- its loads are dummies)
+        auto sched = [&](int i) -> unsigned { return i < nst ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_sched[i]) : SCH_DRAIN; };
+        auto sched_sj = [&](int i) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_sjp[i < nst ? i : nst - 1]); };
+
+        StripRegs<T, FLY> R0, R1, R2;
+        R0.th = R1.th = R2.th = T(0); R0.zz = R1.zz = R2.zz = T(0); R0.sg = R1.sg = R2.sg = T(0);
+        R0.lw = R1.lw = R2.lw = 0u; R0.sh = R1.sh = R2.sh = -1;
+        SB_T(1);                                         // pick, schedule
+        // A step: S1 of block i, barrier, S2 (sums along latitude || queries of the block two up); a drain step
+        // (behind the last block of a run) has no S1 and queries the block one up.  The three register sets take
+        // turns -- as three copies of the step in the loop body, not as a switch or an inner loop: the compiler counts
+        // the loads in flight per program point, and only straight-line rotation with the same loads on every path
+        // lets it wait for block i's loads alone while those of blocks i + 1 and i + 2 stay in flight.  The set just
+        // consumed receives the loads of block i + 3.
+        auto step = [&](StripRegs<T, FLY> &R, int i) __attribute__((always_inline)) {
+            const unsigned ent = sched(i), sj = sched_sj(i);
+            const int pos = (int)(ent & 0xffffu);
+            const int strip = (int)(sj >> 16), jp = (int)(sj & 0xffffu);
+            const bool drain = (ent & SCH_DRAIN) != 0, idle = (ent & SCH_IDLE) != 0;
+            const int qoff = drain ? 1 : 2;
+            const bool qdo = wv >= 3 && wv < 3 + C / 2 && (ent & (drain ? SCH_Q1 : SCH_Q2));
+            BandWords bwd;
+            bwd.a0 = bwd.b0 = bwd.a1 = bwd.b1 = bwd.c0 = bwd.c1 = 0; bwd.sh = 0;
+            if (!idle) {
+                if (ent & SCH_RESTART) lds_barrier();             // the queries of the run before have left the ring
+                bwd = band_issue(strip, jp - qoff);
+                if (!drain) stage(R, ent, jp);
+            }
+            issue(R, sched_sj(i + STRIP_DEPTH));                  // (the one place of this copy of the step that loads)
+            SB_T(2);                                     // S1 (incl. the wait for the block's loads)
+            if (!idle) {
+                lds_barrier();
+                SB_T(3);                                 // barrier
+                if (!drain && wv < 3) vertical(jp);
+#if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
+                else query(pos - qoff, strip, jp - qoff, bwd, qdo);
+#endif
+                SB_T(4);                                 // S2
+#ifdef SB_STAMPS
+                acc[drain ? 5 : 6] += 1;
+#endif
+            }
+        };
+        for (int i = 0; i < nst; i += STRIP_DEPTH) {         // nst is a multiple of three
+            step(R0, i);
+            step(R1, i + 1);
+            step(R2, i + 2);
+        }
+        __syncthreads();                                 // the schedule and the ring are free for the next round
+    }
+
+    SB_T(7);                                             // round tail
+    if (job.fold) {
+        // ---- k_wind's segment lists (k_prep's work on single-domain host-model calls): sub-list `part` holds the
+        // segments with band cells of its contiguous range of the band plane, in ascending order ----
+        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+        const unsigned cap = (unsigned)job.seg_cap;
+        for (int part = G - 1 - (int)blockIdx.x; part < SB_SEG_PARTS; part += G) {
+            if (part < 0) break;
+            const unsigned s0 = (unsigned)part * cap, s1 = min(s0 + cap, nseg);
+            const unsigned per = (cap + STRIP_NT - 1) / STRIP_NT;
+            const unsigned a0 = min(s0 + (unsigned)tid * per, s1), a1 = min(a0 + per, s1);
+            int cnt = 0;
+            for (unsigned sg = a0; sg < a1; ++sg) cnt += job.bandbits[sg] != 0 ? 1 : 0;
+            int total;
+            int at = thc_block_excl_scan<STRIP_NT>(cnt, s_scan, total);
+            SbSegEntry *list = job.seg_list + (size_t)part * cap;
+            for (unsigned sg = a0; sg < a1; ++sg) {
+                const u64 w = job.bandbits[sg];
+                if (w) { SbSegEntry e; e.word = w; e.seg = sg; e.pad = 0; list[at++] = e; }
+            }
+            if (tid == 0) job.seg_count[part] = total;
+        }
+    }
+#ifdef SB_STAMPS
+    SB_T(8);                                             // segment lists
+    if (tid == 0) {
+        acc[9] = w_begin;
+        acc[10] = wall_clock64();
+        for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)blockIdx.x * SB_NSTAMP + i] = acc[i];
+    }
+    if (lane == 0 && blockIdx.x < 64)
+        for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)(1024 + blockIdx.x * NWV + wv) * SB_NSTAMP + i] = acc[i];
+#endif
+}
+
+template <typename T>
+hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st) {
+    const dim3 gr(ncu), bl(STRIP_NT);                   // one persistent workgroup per CU
+    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_strip<T, true, true>), gr, bl, 0, st, job.stats, ncu, job);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true, false>), gr, bl, 0, st, job.stats, ncu, job);
+    else if (job.wind_final) hipLaunchKernelGGL((k_strip<T, false, true>), gr, bl, 0, st, job.stats, ncu, job);
+    else hipLaunchKernelGGL((k_strip<T, false, false>), gr, bl, 0, st, job.stats, ncu, job);
+    return hipGetLastError();
+}
+template hipError_t sb_launch_strip<float>(const DiagJob<float> &, int, hipStream_t);
+template hipError_t sb_launch_strip<double>(const DiagJob<double> &, int, hipStream_t);
+
+// the strip kernel's block grid for a domain of nx x rows interior cells; false: the position plane cannot hold it
+bool sb_strip_shape(int nx, int rows, int *ntx, int *nty) {
+    *ntx = (nx + STRIP_SW - 1) / STRIP_SW;
+    *nty = (rows + STRIP_C - 1) / STRIP_C;
+    return (long long)*ntx * (*nty + 2) <= 65535;
+}

@@ -13,8 +13,7 @@
 // One persistent workgroup per CU (k_thc3, below) works through the active tiles -- ranked by itself from the flags
 // k_scan raised (FOLD) or taken from the list k_prep compacted: tiles that do not touch the coastal band (about
 // 3 in 4) cost nothing.  Default instance: 1024 threads, every tile loaded when its turn comes (PFX = false).
-#include "sb_device.hpp"
-#include "sb_launch.hpp"
+#include "sb_thc_common.hpp"
 
 // k_thc3 tiles are 32 longitudes wide: with the halo a staged row is exactly one 64-lane chunk (H = 16), so
 // no lane of a staging load, an exp or an LDS write is padding.  48 latitudes by default: on the N1280 grid
@@ -42,57 +41,6 @@
 #define THC_TY24 32               // tile rows with a halo of 24 (81 x 81 table entries)
 #define THC_TY32 16               // tile rows with a halo of 32: 81 x 97 table entries are what 160 KB of LDS hold
 
-// ------------------------------------------------------------------------------------
-// Global-memory search for cells whose window outgrows the LDS tile (rare).  Rings are
-// accumulated from the centre outwards; the first radius >= 1 at which the square holds
-// both classes is the reference's final nn.  cap bounds the radius: the reference loop has
-// none and never returns on a one-class grid (SURVEY.md §7 "Hard parts").
-// ------------------------------------------------------------------------------------
-// t0 of one cell of the ghost-celled frame: from the workspace (f2py flavour) or derived on the spot
-template <typename T>
-__device__ __forceinline__ T cell_t0(const DiagJob<T> &job, size_t idx, T sd, T rr) {
-    if (!job.t0_fly) return job.t0[idx];
-    return sb_t0<T>(job.theta[idx], job.z[idx], job.sigma[idx], sd, rr);
-}
-
-template <typename T>
-__device__ __forceinline__ T contrast_global(const DiagJob<T> &job, int x, int y, int cap, T sd, T rr, int &nn_used,
-                                          bool &one_class) {
-    const Geo g = job.g;
-    int X, Y;
-    bool has_l = false, has_s = false;
-    if (sb_map_cell(g, x, y, X, Y)) {
-        if (sb_bit(job.clsbits, g.nw, X, Y)) has_l = true; else has_s = true;
-    }
-    int nn = 0;
-    bool found = false;
-    while (nn < cap) {
-        ++nn;
-        for (int e = -nn; e <= nn; ++e) {
-            const int xs[4] = {x + e, x + e, x - nn, x + nn};
-            const int ys[4] = {y - nn, y + nn, y + e, y + e};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (sb_map_cell(g, xs[q], ys[q], X, Y)) {
-                    if (sb_bit(job.clsbits, g.nw, X, Y)) has_l = true; else has_s = true;
-                }
-        }
-        if (has_l && has_s) { found = true; break; }
-    }
-    nn_used = nn;
-    one_class = !found;
-    sb_map_cell(g, x, y, X, Y);
-    const double c0 = (double)cell_t0(job, (size_t)Y * g.nxh + X, sd, rr);
-    double sl = 0.0, ss = 0.0, nl = 0.0, ns = 0.0;
-    for (int yy = y - nn; yy <= y + nn; ++yy)
-        for (int xx = x - nn; xx <= x + nn; ++xx) {
-            if (!sb_map_cell(g, xx, yy, X, Y)) continue;
-            const double d = (double)cell_t0(job, (size_t)Y * g.nxh + X, sd, rr) - c0;
-            if (sb_bit(job.clsbits, g.nw, X, Y)) { sl += d; nl += 1.0; } else { ss += d; ns += 1.0; }
-        }
-    return (T)(sl / nl - ss / ns);               // 0/0 -> NaN when a class is missing
-}
-
 // ====================================================================================
 // k_thc3: t0 = theta - (gmma*z)*sigmoid(sigma) on the fly, the three summed-area tables, the
 // radius search and the contrast (plus thresholds and state update in a band step).
@@ -115,34 +63,6 @@ __device__ __forceinline__ T contrast_global(const DiagJob<T> &job, int x, int y
 #else
 #define SB_T(i) do { } while (0)
 #endif
-
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// ---- buffer loads: a 128-bit resource descriptor per field (wave-uniform base + size), a 32-bit byte offset per
-// lane and a scalar byte offset per row.  One instruction per load, no 64-bit address arithmetic: the staging of a
-// tile is issue-bound, and a row's offset is the same for all 64 lanes of the wave that owns it.
-typedef unsigned int sb_u2 __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ __forceinline__ T sb_buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
-template <>
-__device__ __forceinline__ double sb_buf_ld<double>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const sb_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
-template <>
-__device__ __forceinline__ float sb_buf_ld<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sb_make_rsrc(const void *p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0xfffffff0ull ? 0xfffffff0ull : bytes), 0x00020000);
-}
-
-template <bool FLY>
-struct ThcBufs {
-    __amdgpu_buffer_rsrc_t th, zz, sg, cls;       // theta (FLY) or t0; z; sigma; land-side plane
-};
 
 // everything a thread holds of a tile between the issue of its loads and A1
 template <typename T, int NC, int NCH, bool FLY>
@@ -245,39 +165,6 @@ __device__ __forceinline__ void thc_issue(const DiagJob<T> &job, const ThcBufs<F
     thc_issue_begin<T, TX, TY, H, NT, FLY, RPW, NCH>(job, B, tile, R, C);
 #pragma unroll
     for (int ri = 0; ri < RPW; ++ri) thc_issue_row<T, H, FLY, RPW, NCH>(job, B, C, wvu, ri, R);
-}
-
-// reciprocal of a small positive integer held in a double: v_rcp_f64 and two Newton steps (within an ulp of 1/n)
-__device__ __forceinline__ double sb_inv(double n) {
-    double q = __builtin_amdgcn_rcp(n);
-    q = __builtin_fma(q, __builtin_fma(-n, q, 1.0), q);
-    q = __builtin_fma(q, __builtin_fma(-n, q, 1.0), q);
-    return q;
-}
-
-// largest value of a wave, valid in lane 63 (DPP, no LDS crossbar)
-__device__ __forceinline__ int sb_wave_max_to_last(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
-    return v;                                    // values are >= 0, lanes without a source contribute 0
-}
-
-// exclusive prefix of one int per thread over an NT-thread workgroup; total in `total`.  Two barriers.
-template <int NT>
-__device__ __forceinline__ int thc_block_excl_scan(int v, int *s_w, int &total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int incl = sb_wave_scan_add(v);
-    __syncthreads();
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    const int wt = lane < NT / SB_WAVE ? s_w[lane] : 0;
-    const int wincl = sb_wave_scan_add(wt);
-    total = __shfl(wincl, NT / SB_WAVE - 1);
-    return incl - v + __shfl(wincl, wv) - __shfl(wt, wv);
 }
 
 #define THC_MAXCNT 256            // FOLD: 64-bit words of the active-tile bit plane a workgroup can hold (the host checks)
@@ -885,59 +772,26 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
 template <typename T, int TX, int TY, int H, int NT>
 static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
     const dim3 gr(nblocks), bl(NT);
-    if (job.t0_fly && job.wind_final && job.no_prefetch && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.t0_fly && job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.t0_fly && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.wind_final && job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.no_prefetch) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.t0_fly && job.wind_final && job.fold) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
-    else hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    // (tile list and sigmoid scalars from k_prep, every tile loaded when its turn comes: FOLD = false, PFX = false)
+    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, true, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else if (job.wind_final) hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, true, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
+    else hipLaunchKernelGGL((k_thc3<T, TX, TY, H, NT, false, false, false, false>), gr, bl, 0, st, (const int *)job.tile_list, job.stats, nblocks, job);
 }
 
+// LDS halos of 24 and 32 cells (distance fields made with windows of 17 .. 31 cells: the N2560 grid); radii up to 16
+// are the strip kernel's (sb_strip_kernel.hip)
 template <typename T>
-hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, int nt, hipStream_t st) {
+hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st) {
     const int nblocks = ncu;                     // one persistent workgroup per CU
-    // 512 threads (8 waves of up to 256 registers) or 1024 (16 waves of up to 128); the wide-halo tiles (two 64-lane
-    // chunks per staged row) need the LDS the second set of band totals would take
-    if (H <= 8) {
-        if (nt == 1024) launch_thc3<T, THC_TX, THC_TY, 8, 1024>(job, nblocks, st);
-        else launch_thc3<T, THC_TX, THC_TY, 8, 512>(job, nblocks, st);
-    } else if (H <= 16 && job.thc_ty == THC_TYS) {
-        if (nt == 1024) launch_thc3<T, THC_TX, THC_TYS, 16, 1024>(job, nblocks, st);
-        else launch_thc3<T, THC_TX, THC_TYS, 16, 512>(job, nblocks, st);
-    } else if (H <= 16 && job.thc_ty == THC_TYL) {
-        if (nt == 1024) launch_thc3<T, THC_TX, THC_TYL, 16, 1024>(job, nblocks, st);
-        else launch_thc3<T, THC_TX, THC_TYL, 16, 512>(job, nblocks, st);
-    } else if (H <= 16) {
-        if (nt == 1024) launch_thc3<T, THC_TX, THC_TY, 16, 1024>(job, nblocks, st);
-        else launch_thc3<T, THC_TX, THC_TY, 16, 512>(job, nblocks, st);
-    }
-    else if (H <= 24) launch_thc3<T, THC_TX, THC_TY24, 24, 512>(job, nblocks, st);
+    if (H <= 24) launch_thc3<T, THC_TX, THC_TY24, 24, 512>(job, nblocks, st);
     else launch_thc3<T, THC_TX, THC_TY32, 32, 512>(job, nblocks, st);   // H == 32
     return hipGetLastError();
 }
-template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, int, hipStream_t);
-template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, int, hipStream_t);
+template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, hipStream_t);
+template hipError_t sb_launch_thc<double>(const DiagJob<double> &, int, int, hipStream_t);
 
-// can k_thc3 take over k_prep's work for this many tiles, partial moments and workgroups?  (threads: of its workgroups)
-bool sb_thc_can_fold(int ntiles, int nparts, int nblocks, int threads) {
-    if (threads != 512 && threads != 1024) return false;
-    const int nch = (ntiles + threads - 1) / threads;
-    return nch <= 32 && nch * (threads / SB_WAVE) <= THC_MAXCNT && nparts <= threads && nblocks >= 1;
-}
-
-void sb_thc_tile_shape(int H, int nx, int rows, int ncu, int *tx, int *ty) {
-    if (H <= 16) {
-        *tx = THC_TX;
-        *ty = THC_TY;
-        // about a quarter of the tiles touch the coastal band: while even twice the tile count would leave
-        // workgroups without a tile, use the 32-row tiles (H = 16 only)
-        const long long full = (long long)((nx + THC_TX - 1) / THC_TX) * ((rows + THC_TYL - 1) / THC_TYL);
-        if (H > 8 && full <= 2LL * ncu) *ty = THC_TYS;
-    }
-    else if (H <= 24) { *tx = THC_TX; *ty = THC_TY24; }
-    else { *tx = THC_TX; *ty = THC_TY32; }
+void sb_thc_tile_shape(int H, int *tx, int *ty) {
+    *tx = THC_TX;
+    *ty = H <= 24 ? THC_TY24 : THC_TY32;
 }

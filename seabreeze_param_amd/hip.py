@@ -97,22 +97,6 @@ class Context:
     def set_search_radius_hint(self, r: int):
         self._chk(self.lib.sb_set_search_radius_hint(self.h, C.c_int(r)), "sb_set_search_radius_hint")
 
-    def set_tile_rows(self, rows: int):
-        """0: automatic, 32 / 48 / 64: force the contrast kernel's tile height (tuning / test knob)."""
-        self._chk(self.lib.sb_set_tile_rows(self.h, C.c_int(rows)), "sb_set_tile_rows")
-
-    def set_thc_prefetch(self, on: bool):
-        """Register prefetch of the next tile in the contrast kernel (tuning / test knob; default off)."""
-        self._chk(self.lib.sb_set_thc_prefetch(self.h, C.c_int(1 if on else 0)), "sb_set_thc_prefetch")
-
-    def set_thc_threads(self, threads: int):
-        """512 or 1024 threads per contrast-kernel workgroup, 0 = default (1024) (tuning / test knob)."""
-        self._chk(self.lib.sb_set_thc_threads(self.h, C.c_int(threads)), "sb_set_thc_threads")
-
-    def set_overlap(self, on: bool):
-        """Contrast kernel and level-search kernel side by side on two streams (measurement / test knob)."""
-        self._chk(self.lib.sb_set_overlap(self.h, C.c_int(1 if on else 0)), "sb_set_overlap")
-
     def set_fold(self, on: bool):
         """k_prep's work inside the contrast kernel (default) or as a kernel of its own (measurement / test knob)."""
         self._chk(self.lib.sb_set_fold(self.h, C.c_int(1 if on else 0)), "sb_set_fold")

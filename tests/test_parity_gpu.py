@@ -107,7 +107,7 @@ SHAPES = [(96, 72, 3), (256, 192, 5), (130, 75, 2), (63, 40, 1), (200, 33, 4), (
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
+def test_wrapper_flavour_fp64(hipctx, oracles, shape, contrast_variant):
     nx, ny, nz = shape
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt, fractional_coast=True)
@@ -116,6 +116,7 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
     maxdist = 180.0 if nx >= 1024 else 700.0
     cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=maxdist)
     _assert_close64(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=maxdist), cdist, "cdist")
+    hipctx.set_search_radius_hint(contrast_variant)          # (get_dist left its own window as the hint)
     p = synth.pressure_1d(nz, dt)
     so, sh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
     for tn in range(1, 6):
@@ -132,34 +133,22 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, tile_rows):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[(64, 1024, True, False), (48, 1024, True, False), (32, 1024, True, False), (48, 512, True, False),
-                        (32, 512, True, True), (48, 512, True, True), (48, 1024, True, True), (64, 512, True, True),
-                        (48, 1024, False, False), (32, 512, False, True), (48, 1024, "overlap", False), (32, 512, "overlap", False)],
-                ids=["tiles32x64", "tiles32x48", "tiles32x32", "tiles32x48-512thr",
-                     "tiles32x32-512thr-prefetch", "tiles32x48-512thr-prefetch", "tiles32x48-prefetch", "tiles32x64-512thr-prefetch",
-                     "tiles32x48-kprep", "tiles32x32-512thr-prefetch-kprep", "tiles32x48-overlap", "tiles32x32-512thr-overlap"])
-def tile_rows(request, hipctx):
-    """Every height of the contrast kernel's LDS tiles, both of its workgroup sizes, with and without its register
-    prefetch, k_prep's work inside the contrast kernel (the default for host-model calls on one domain) or as a kernel
-    of its own, and the overlap mode (contrast kernel beside the level walk on two streams): by default small
-    grids get the 32-row tiles and the benchmark grid the 48-row ones, so the oracle comparisons run under each."""
-    rows, threads, fold, prefetch = request.param
-    hipctx.set_tile_rows(rows)
-    hipctx.set_thc_threads(threads)
-    hipctx.set_thc_prefetch(prefetch)
-    hipctx.set_fold(fold is True)
-    hipctx.set_overlap(fold == "overlap")      # contrast kernel and level walk side by side, then k_final
-    yield rows
-    hipctx.set_tile_rows(0)
-    hipctx.set_thc_threads(0)
-    hipctx.set_thc_prefetch(False)
+@pytest.fixture(params=[(16, True), (16, False), (24, False)], ids=["strip", "strip-kprep", "tiles-halo24"])
+def contrast_variant(request, hipctx):
+    """The contrast kernels the oracle comparisons run under: the marching-strip kernel (radius hints up to 16) doing
+    k_prep's work itself (the default for host-model calls on one domain) or with k_prep as a kernel of its own, and
+    the tile kernel with its 24-cell halo (what a radius hint of 17..24 selects).  Results never depend on the choice."""
+    hint, fold = request.param
+    hipctx.set_search_radius_hint(hint)
+    hipctx.set_fold(fold)
+    yield hint
+    hipctx.set_search_radius_hint(16)
     hipctx.set_fold(True)
-    hipctx.set_overlap(False)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("bnd", [hip.SB_BND_GLOBAL, hip.SB_BND_WRAPPER])
-def test_generic_flavour_fp64(hipctx, oracles, shape, bnd, tile_rows):
+def test_generic_flavour_fp64(hipctx, oracles, shape, bnd, contrast_variant):
     nx, ny, nz = shape
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)
@@ -168,6 +157,7 @@ def test_generic_flavour_fp64(hipctx, oracles, shape, bnd, tile_rows):
     kw = 4 if nx < 1024 else 6
     cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=kw)   # generic: fixed +-halo window
     _assert_close64(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=kw), cdist, "cdist")
+    hipctx.set_search_radius_hint(contrast_variant)          # (get_dist left its own window as the hint)
     cdist[np.abs(cdist) > 180.0] = 12000.0
     p = synth.pressure_3d(st, nz, dt)
     so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
@@ -235,7 +225,7 @@ def test_generic_flavour_fp32(hipctx, oracles, shape):
 # ----------------------------------------------------------------------------------------
 # halo'd (band) arrays, search radius beyond the LDS tile, degenerate grids
 # ----------------------------------------------------------------------------------------
-def test_halo_mode_matches_oracle(hipctx, oracles, tile_rows):
+def test_halo_mode_matches_oracle(hipctx, oracles, contrast_variant):
     nx, ny, nz, h = 160, 96, 3, 7
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx + 2 * h, ny + 2 * h, dt)          # a bigger field whose rim serves as ghosts
@@ -433,7 +423,7 @@ def test_halo_32_holds_radii_up_to_32_in_lds(hipctx, oracles):
 
 
 def test_wide_halo_path_matches_oracle(hipctx, oracles):
-    """A radius hint of 17..24 selects the LDS halo of 24 cells (k_thc2 with 32 x 32 tiles): same numbers."""
+    """A radius hint of 17..24 selects the tile contrast kernel with its LDS halo of 24 cells (32 x 32 tiles): same numbers."""
     nx, ny, nz = 256, 192, 3
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)
@@ -494,10 +484,9 @@ def _omp_oracle(prec):
 
 @pytest.mark.parametrize("shape", [(2560, 1920, 56), (1024, 768, 56)], ids=["N1280x56", "N512x56"])
 def test_baseline_configs_fp64_vs_oracle(hipctx, shape):
-    """BASELINE configs[2] (the headline: k_wind walking 56 levels in 7 full batches, 48-row k_thc3 tiles,
-    about 670 of them active) and configs[1], default tiles, both workgroup sizes of k_thc3 (the default one without, the
-    other with the register prefetch): first step,
-    ordinary step and a step whose target_time branch fires (timestep 1440 s: tn = 15), all four outputs."""
+    """BASELINE configs[2] (the headline: k_wind walking 56 levels in 7 full batches, the strip contrast kernel
+    marching about 1650 active blocks) and configs[1]: first step, ordinary step and a step whose target_time
+    branch fires (timestep 1440 s: tn = 15), all four outputs."""
     nx, ny, nz = shape
     dt = np.float64
     orc = _omp_oracle(8)
@@ -505,24 +494,15 @@ def test_baseline_configs_fp64_vs_oracle(hipctx, shape):
     coast = hipctx.get_edges(st.landfrac, st.icefrac)
     cdist = hipctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     p = synth.pressure_3d(st, nz, dt)
-    so = _states(ny, nx, dt, 4)
-    # the default instance (1024 threads, no register prefetch) and the 512-thread instance with its prefetch
-    sh = {(1024, False): _states(ny, nx, dt, 4), (512, True): _states(ny, nx, dt, 4)}
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
     for tn in (1, 2, 15):
         th = synth.theta_step(st, tn, dt)
         u, v = synth.wind_step(st, nz, tn, dt)
         orc.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1, omp=True)
-        for (threads, prefetch), s4 in sh.items():
-            hipctx.set_thc_threads(threads)
-            hipctx.set_thc_prefetch(prefetch)
-            try:
-                hipctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *s4, halo=0, bnd=hip.SB_BND_GLOBAL)
-            finally:
-                hipctx.set_thc_threads(0)
-                hipctx.set_thc_prefetch(False)
-            for a, b, nm in zip(s4, so, ("ws", "wd", "thc", "sb_con")):
-                _assert_close64(a, b, f"{shape} threads={threads} prefetch={prefetch} tn={tn} {nm}")
-            assert np.array_equal(s4[3] != 0, so[3] != 0), (threads, tn)
+        hipctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+            _assert_close64(a, b, f"{shape} tn={tn} {nm}")
+        assert np.array_equal(sh[3] != 0, so[3] != 0), tn
         del u, v
     c = hipctx.last_counters()
     assert c["global_path_cells"] == 0 and c["one_class_cells"] == 0
