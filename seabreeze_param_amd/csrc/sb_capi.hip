@@ -62,7 +62,7 @@ struct sb_ctx {
     // what the last diag / band step enqueued (sb_last_step_report)
     int rep_launches = 0, rep_rccl = 0, rep_groups = 0, rep_copies = 0;
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps, jobcopy;
     int tiles_n = 0, tiles_strip = -1, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
@@ -225,6 +225,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
         if ((rc = ensure(c, c->t0, ncell * sizeof(T)))) return rc;
         job.t0 = (T *)c->t0.p;
     }
+    if ((rc = ensure(c, c->jobcopy, sizeof(DiagJob<double>)))) return rc;
+    job.self = (DiagJob<T> *)c->jobcopy.p;
     job.stamps = nullptr;
 #ifdef SB_STAMPS
     if ((rc = ensure(c, c->stamps, (size_t)4096 * SB_NSTAMP * sizeof(long long)))) return rc;
@@ -942,7 +944,7 @@ int sb_destroy(sb_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->nws, &c->nwd, &c->coastbits, &c->tile_list,
-                      &c->seg_list, &c->stamps})
+                      &c->seg_list, &c->stamps, &c->jobcopy})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);

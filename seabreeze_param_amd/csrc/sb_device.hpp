@@ -282,8 +282,30 @@ struct DiagJob {
     const Moments *fold_partials;   // k_scan's per-workgroup moments (fold_nparts of them; 0: the scalars in stats stand)
     int fold_nparts;
     T *stats_out;                   // where workgroup 0 publishes the sigmoid scalars
+    DiagJob<T> *self;               // where k_scan leaves a copy of this job in device memory: kernels that take only the
+                                    // hot part of it by value (k_strip) read the rest from there, rarely
     int *counters;                  // [0] cells on the global-memory path, [1] one-class cells
     long long *stamps;              // diagnostic build (-DSB_STAMPS) only: SB_NSTAMP clock sums per k_thc3 workgroup
+};
+
+// What the strip contrast kernel needs on every step, passed by value (about 50 scalar registers; the whole DiagJob
+// by value costs the kernel some 100 spilled scalar registers).
+template <typename T>
+struct StripJob {
+    Geo g;
+    const T *theta, *z, *sigma;     // theta: the t0 plane unless t0 is derived while staging
+    const uint64_t *clsbits, *bandbits;
+    T *thc;
+    int *flags;                     // strip-major block flags (DiagJob::tile_nnmax)
+    int ntx, nty;                   // strips, blocks per strip
+    int fold, fold_nparts, ngath, seg_cap;
+    const T *stats;
+    T *stats_out;
+    const Moments *fold_partials, *gath;
+    SbSegEntry *seg_list;
+    int *seg_count;
+    const DiagJob<T> *cold;         // the whole job in device memory (k_scan wrote it): slow path, band-step update
+    long long *stamps;              // diagnostic build only
 };
 
 __device__ __forceinline__ int sb_bit(const uint64_t *bits, int nw, int X, int Y) {
@@ -306,9 +328,8 @@ __host__ __device__ inline T sb_modulo(T a, T p) {
 }
 
 // 1/(1+exp(y)) in the working precision.  For doubles: exp by argument reduction to |r| <= ln2/2 (two-part ln2,
-// fused), a degree-13 Taylor polynomial (truncation 4e-18) and v_ldexp_f64; the reciprocal by v_rcp_f64 and two
-// Newton steps.  About 30 instructions against about 90 for libm's exp plus an IEEE division, and within 2 ulp
-// of them -- a sixth of the fp64 work of staging a coastal tile was this expression.
+// fused), a degree-11 Taylor polynomial and v_ldexp_f64; the reciprocal by v_rcp_f64 and a Newton step.  About 30
+// instructions against about 90 for libm's exp plus an IEEE division, and within a few ulp of them.
 template <typename T>
 __device__ __forceinline__ T sb_logistic_of_neg(T y) {        // returns 1 / (1 + exp(y))
     return T(1) / (T(1) + exp(y));
@@ -318,24 +339,21 @@ __device__ __forceinline__ double sb_logistic_of_neg<double>(double y) {
     y = fmin(fmax(y, -708.0), 700.0);                         // beyond: 1 or 0 to the last bit
     const double n = __builtin_rint(y * 1.4426950408889634);
     double r = __builtin_fma(-n, 0.6931471805599453, y);
-    r = __builtin_fma(-n, 2.3190468138462996e-17, r);
-    double p = 1.6059043836821613e-10;                        // 1/13!
-    p = __builtin_fma(p, r, 2.08767569878681e-09);            // 1/12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);           // 1/11!
-    p = __builtin_fma(p, r, 2.755731922398589e-07);           // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);          // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873e-05);            // 1/8!
-    p = __builtin_fma(p, r, 1.984126984126984e-04);           // 1/7!
-    p = __builtin_fma(p, r, 1.388888888888889e-03);           // 1/6!
-    p = __builtin_fma(p, r, 8.333333333333333e-03);           // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);          // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);          // 1/3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
+    r = __builtin_fma(-n, 2.3190468138462996e-17, r);         // |r| <= ln2/2
+    // exp(r) by its Taylor polynomial of degree 11 (truncation r^12/12! < 7e-15 relative), evaluated in Estrin's
+    // scheme: the kernels that call this are bound by the latency of their dependent chains, not by instruction
+    // issue, and the tree is 5 fused multiply-adds deep where Horner's rule is 11
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double p01 = __builtin_fma(r, 1.0, 1.0);
+    const double p23 = __builtin_fma(r, 1.6666666666666666e-01, 0.5);
+    const double p45 = __builtin_fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+    const double p67 = __builtin_fma(r, 1.984126984126984e-04, 1.388888888888889e-03);
+    const double p89 = __builtin_fma(r, 2.7557319223985893e-06, 2.48015873015873e-05);
+    const double pab = __builtin_fma(r, 2.505210838544172e-08, 2.755731922398589e-07);
+    const double q0 = __builtin_fma(r2, p23, p01), q1 = __builtin_fma(r2, p67, p45), q2 = __builtin_fma(r2, pab, p89);
+    const double p = __builtin_fma(r8, q2, __builtin_fma(r4, q1, q0));
     const double x = 1.0 + ldexp(p, (int)n);
-    double q = __builtin_amdgcn_rcp(x);
-    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
+    double q = __builtin_amdgcn_rcp(x);                       // v_rcp_f64 and one Newton step: relative error < 1e-15
     q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
     return q;
 }

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     const unsigned nwaves = gridDim.x * NWV;
     const size_t pl = (size_t)g.nx * g.ny;
     if (blockIdx.x == 0 && threadIdx.x == 0 && job.ticket) *job.ticket = 0;   // spare device word, zeroed every call
+    // a copy of the job in device memory for the kernels that take only its hot part by value (the job is this
+    // kernel's first argument: the argument segment starts with it)
+    if (blockIdx.x == 0 && job.self && threadIdx.x < sizeof(DiagJob<T>) / 4)
+        ((unsigned *)job.self)[threadIdx.x] = ((const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_kernarg_segment_ptr())[threadIdx.x];
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     double s1 = 0.0, s2 = 0.0, mn = 1.0e308, mx = -1.0e308;
     int cnt = 0;

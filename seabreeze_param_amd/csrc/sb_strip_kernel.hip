@@ -40,9 +40,9 @@
 #define STRIP_RING 128            // ring rows (8 blocks): a query of block j reads rows of blocks j-2 .. j+1 while
                                   // block j+3 may already be written
 #define STRIP_P (STRIP_W + 1)     // table pitch: column 0 is the zero column
-#define STRIP_MAXW 1024           // 64-bit words of the position plane a workgroup can hold (65,535 positions)
-#define STRIP_SCHED 512           // staged blocks of one round of a workgroup
-#define STRIP_ROUND 120           // active blocks of one round (at most 3 x 120 staged blocks + 120 drain + 3 warm-up steps)
+#define STRIP_MAXW 768            // 64-bit words of the position plane a workgroup can hold (49,151 positions)
+#define STRIP_SCHED 384           // steps of one round of a workgroup
+#define STRIP_ROUND 90            // active blocks of one round (at most 3 x 90 staged blocks + 90 drain + 3 warm-up + 2 padding steps)
 #define STRIP_FB 40               // fractional bits of the fixed-point t0
 #define STRIP_DEPTH 3             // blocks of inputs in flight per wave
 
@@ -54,11 +54,55 @@ typedef unsigned long long u64;
 #define SB_T(i) do { } while (0)
 #endif
 
+// The fp64 constants of a staged row -- the logistic's argument reduction and Taylor coefficients, the fixed-point
+// conversion -- live in constant memory and are fetched by scalar loads where they are used (two s_load_dwordx16 per
+// row, from the scalar cache).  As literals they are loop invariants the compiler keeps in some 40 scalar registers for
+// the whole march, and the registers it then has to spill cost the staging code a quarter of its vector instructions
+// (v_readlane reloads).  The pointer is made opaque per use so that the loads are not hoisted.
+__constant__ double sb_strip_k[20] = {
+    1.4426950408889634, 0.6931471805599453, 2.3190468138462996e-17, -708.0, 700.0,            // 0..4: log2(e), ln2 hi, lo, clamps
+    1.6666666666666666e-01, 4.1666666666666664e-02, 8.333333333333333e-03, 1.388888888888889e-03,     // 5..8: 1/3! .. 1/6!
+    1.984126984126984e-04, 2.48015873015873e-05, 2.7557319223985893e-06, 2.755731922398589e-07,     // 9..12: 1/7! .. 1/10!
+    2.505210838544172e-08,                                                                         // 13: 1/11!
+    -1024.0, 1024.0, 0x1p40, 0x1.8p52,                                                               // 14..17: fixed point
+    -0.0060956, 0.0};                                                                               // 18: gmma (ref :138)
+typedef const __attribute__((address_space(4))) double *sb_cdp;
+
+// 1 / (1 + exp(y)): as sb_logistic_of_neg<double> (sb_device.hpp), constants from the table
+__device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
+    y = fmin(fmax(y, -708.0), 700.0);                         // (literals: known not to be NaN, no canonicalisation)
+    const double n = __builtin_rint(y * k[0]);
+    double r = __builtin_fma(-n, k[1], y);
+    r = __builtin_fma(-n, k[2], r);                           // |r| <= ln2/2
+    // exp(r), degree 11, as E(r^2) + r O(r^2): two Horner chains of five, every multiply-add with ONE constant (a
+    // scalar operand; a second one would have to be copied to vector registers first)
+    const double r2 = r * r;
+    double e = __builtin_fma(r2, k[12], k[10]);               // 1/10!, 1/8!
+    double o = __builtin_fma(r2, k[13], k[11]);               // 1/11!, 1/9!
+    e = __builtin_fma(e, r2, k[8]);  o = __builtin_fma(o, r2, k[9]);      // 1/6!, 1/7!
+    e = __builtin_fma(e, r2, k[6]);  o = __builtin_fma(o, r2, k[7]);      // 1/4!, 1/5!
+    e = __builtin_fma(e, r2, 0.5);   o = __builtin_fma(o, r2, k[5]);      // 1/2!, 1/3!
+    e = __builtin_fma(e, r2, 1.0);   o = __builtin_fma(o, r2, 1.0);
+    const double p = __builtin_fma(o, r, e);
+    const double x = 1.0 + ldexp(p, (int)n);
+    double q = __builtin_amdgcn_rcp(x);                       // v_rcp_f64 and one Newton step: relative error < 1e-15
+    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
+    return q;
+}
+// t0 = theta - (gmma*z)*sigmoid(sigma)   ref: generic/sea_breeze_diag.f90:166-167,478-480 (as sb_t0)
+__device__ __forceinline__ double strip_t0(double theta, double z, double sigma, double sd, double r, sb_cdp k) {
+    if (z == 0.0) return theta;
+    return theta - ((k[18] * z) * strip_logistic_of_neg(-sd * (sigma - r), k));
+}
+__device__ __forceinline__ float strip_t0(float theta, float z, float sigma, float sd, float r, sb_cdp) {
+    return sb_t0<float>(theta, z, sigma, sd, r);
+}
+
 // t0 (K) -> fixed point.  fma rounds x * 2^40 + 1.5 * 2^52 to an integer held in the mantissa (|x| <= 1024).
-__device__ __forceinline__ u64 sb_to_fixed(double x) {
+__device__ __forceinline__ u64 sb_to_fixed(double x, sb_cdp k) {
     x = fmin(fmax(x, -1024.0), 1024.0);
-    const double y = __builtin_fma(x, 0x1p40, 0x1.8p52);
-    return (u64)(__double_as_longlong(y) - __double_as_longlong(0x1.8p52));
+    const double y = __builtin_fma(x, k[16], k[17]);
+    return (u64)(__double_as_longlong(y) - 0x4338000000000000ll);
 }
 
 // inclusive prefix sums over the 64 lanes of a wave of two 64-bit integers at once: per step and value one
@@ -102,7 +146,7 @@ __device__ __forceinline__ int strip_pick(const u64 *s_bits, int nwords, int r, 
         const int incl = sb_wave_scan_add(pc);
         const int before = run + incl - pc;
         run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
-        const u64 hit = __ballot(before <= r && r < before + pc);
+        const u64 hit = __builtin_amdgcn_ballot_w64(before <= r && r < before + pc);
         if (hit) {                                               // wave-uniform; one lane of one chunk
             const int src = __ffsll((unsigned long long)hit) - 1;
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, src);
@@ -110,7 +154,7 @@ __device__ __forceinline__ int strip_pick(const u64 *s_bits, int nwords, int r, 
             const u64 word = ((u64)hi << 32) | lo;
             const int n = r - __builtin_amdgcn_readlane(before, src);
             const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
-            const u64 sel = __ballot(me);
+            const u64 sel = __builtin_amdgcn_ballot_w64(me);
             pos = (k0 + src) * 64 + __ffsll((unsigned long long)sel) - 1;
             break;
         }
@@ -127,38 +171,51 @@ struct StripRegs {
     int sh;                        // the cell's bit in lw; -1: no such cell
 };
 
-// schedule entry of a staged block: position | flags
+// schedule entry of a step: position | flags
 #define SCH_Q2 (1u << 16)          // the block two positions up is active: its band cells are queried in this step's S2
 #define SCH_RESTART (1u << 17)     // the block before is not staged: the tables start afresh here
 #define SCH_DRAIN (1u << 18)       // no block: the step behind the last block of a run, in which ...
 #define SCH_Q1 (1u << 19)          // ... the block one position up (the run's last active one) is queried
 #define SCH_IDLE (1u << 20)        // nothing but the loads of the block three steps on (warm-up and padding steps)
-#define SCH_NONE 0xffffffffu
+
+typedef const __attribute__((address_space(4))) u64 *cu64p;          // read-only planes: scalar loads
+
+// A cell whose window outgrows the tables (none on a grid whose distance field was made with a window of at most 15
+// cells) is marked during the march -- a NaN of this payload in thc -- and handled after it, by the one copy of the
+// global-memory search that the kernel holds (three inlined copies inside the march's loop tripled the code there, and
+// a call would have the compiler wait for the prefetched blocks around it).
+template <typename T> __device__ __forceinline__ T strip_mark();
+template <> __device__ __forceinline__ double strip_mark<double>() { return __longlong_as_double(0x7ff85ea5b4ee2e00ll); }
+template <> __device__ __forceinline__ float strip_mark<float>() { return __uint_as_float(0x7fc5ea5bu); }
+__device__ __forceinline__ bool strip_is_mark(double v) { return __double_as_longlong(v) == 0x7ff85ea5b4ee2e00ll; }
+__device__ __forceinline__ bool strip_is_mark(float v) { return __float_as_uint(v) == 0x7fc5ea5bu; }
 
 template <typename T, bool FLY, bool WF>     // FLY: t0 from theta, z, sigma while staging; WF: k_wind applies the update
-__global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats, int G, DiagJob<T> job) {
+__global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
-    static_assert(NWV == C, "one staged row per wave");
+    constexpr int RM = STRIP_RING - 1;
+    static_assert(NWV == C && SW == 32, "one staged row per wave, 32 owned columns");
     __shared__ u64 sA[STRIP_RING * P];                 // prefix sums of t0 (fixed point), every cell
     __shared__ u64 sL[STRIP_RING * P];                 // ... land-side cells
     __shared__ unsigned short sC[STRIP_RING * P];      // ... land-side count (modulo 2^16: a window holds < 2^16 cells)
     __shared__ u64 s_land[STRIP_RING];                 // land-side bits of every ring row
     __shared__ u64 s_bits[STRIP_MAXW];                 // the active blocks as a bit plane
-    __shared__ unsigned s_sched[STRIP_SCHED];          // staged blocks of the round: position | flags
-    __shared__ unsigned s_sjp[STRIP_SCHED];            // ... strip << 16 | block within the padded strip
+    __shared__ uint2 s_ent[STRIP_SCHED];               // steps of the round: x = position | flags, y = strip << 16 | block
+                                                       // within the padded strip
+    __shared__ unsigned short s_cell[3][SW * C];       // the band cells of the block a step queries, compacted (three steps in flight)
     __shared__ Moments s_wpart[NWV];
     __shared__ int s_scan[NWV];
-    __shared__ int s_misc[4];
+    __shared__ int s_misc[8];                          // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked
     __shared__ T s_sdr[2];
     static_assert(sizeof(u64) * (2 * STRIP_RING * P + STRIP_RING + STRIP_MAXW) + 2 * STRIP_RING * P + 8 * STRIP_SCHED +
-                          sizeof(Moments) * NWV + 4 * NWV + 16 + 16 <= 160 * 1024,
+                          6 * SW * C + sizeof(Moments) * NWV + 4 * NWV + 32 + 16 <= 160 * 1024,
                   "k_strip: LDS of one workgroup");
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int npad = job.thc_nty + 2;                  // blocks of a strip incl. the virtual ones above and below
-    const int npos = job.thc_ntx * npad;
+    const int npad = job.nty + 2;                      // blocks of a strip incl. the virtual ones above and below
+    const int npos = job.ntx * npad;
 
 #ifdef SB_STAMPS
     long long acc[SB_NSTAMP], t_last = clock64();
@@ -187,8 +244,8 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
                 if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
             }
         }
-    } else if (FLY) { sd = stats[0]; rr = stats[1]; }
-    const int nch = (npos + STRIP_NT - 1) / STRIP_NT;            // <= 64 (host)
+    } else if (FLY) { sd = job.stats[0]; rr = job.stats[1]; }
+    const int nch = (npos + STRIP_NT - 1) / STRIP_NT;            // <= STRIP_MAXW / 16 (host)
     {
         u64 mine = 0;
         for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
@@ -196,7 +253,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = (base + j) * STRIP_NT + tid;
-                f[j] = job.tile_nnmax[i < npos ? i : npos - 1];
+                f[j] = job.flags[i < npos ? i : npos - 1];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -205,12 +262,13 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
             }
         }
         for (int c = 0; c < nch; ++c) {
-            const u64 b = __ballot((mine >> c) & 1ull);
+            const u64 b = __builtin_amdgcn_ballot_w64((mine >> c) & 1ull);
             if (lane == 0) s_bits[c * NWV + wv] = b;
         }
     }
     // the zero column of the three tables (never written again) while the flags travel
     for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
+    if (tid == 0) s_misc[4] = 0;
     if (fold_stats) wave_total_shifted_store(pm, s_wpart);
     __syncthreads();
     if (fold_stats) {
@@ -222,81 +280,139 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
     } else if (FLY && job.ngath > 0) { sd = s_sdr[0]; rr = s_sdr[1]; }
     const int nwords = nch * NWV;
-    // this workgroup's share of the active blocks: ranks [r0, r1) in strip-major order
-    int nact = 0;
-    for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) nact += (k0 + lane < nwords) ? __popcll(s_bits[k0 + lane]) : 0;
-    nact = sb_wave_scan_add(nact);
-    nact = __builtin_amdgcn_readlane(nact, SB_WAVE - 1);
-    const int r_begin = (int)(((long long)blockIdx.x * nact) / G), r_end = (int)(((long long)(blockIdx.x + 1) * nact) / G);
+    SB_T(11);                                            // flags -> plane, statistics
+    // ---- prologue 2: this workgroup's share.  The unit of cost is a STAGED block (an active block or a neighbour of
+    // one): workgroup b takes the active blocks that lie between the staged blocks of ranks b S / G and (b+1) S / G
+    // in strip-major order, so every workgroup marches about S / G blocks (plus at most two where a run is cut) --
+    // an equal share of ACTIVE blocks left the workgroup with the most short runs with 15 blocks against a mean of 10.
+    // Per word of the plane: active and staged blocks before it, packed (low / high 16 bits), by one workgroup scan;
+    // the array lies where the cell lists of the march will (they are not in use yet).
+    unsigned *s_pre = (unsigned *)&s_cell[0][0];
+    static_assert(sizeof(s_cell) >= sizeof(unsigned) * STRIP_MAXW, "the prefix array fits where the cell lists lie");
+    auto stage_word = [&](int k) -> u64 {                // staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
+        const u64 a = s_bits[k], pv = k > 0 ? s_bits[k - 1] : 0ull, nx = k + 1 < nwords ? s_bits[k + 1] : 0ull;
+        return a | (a << 1) | (pv >> 63) | (a >> 1) | (nx << 63);
+    };
+    int tot_packed;
+    {
+        unsigned v = 0;
+        if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
+        const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tot_packed);
+        if (tid < nwords) s_pre[tid] = (unsigned)ex;
+        __syncthreads();
+    }
+    const int nact = tot_packed & 0xffff, nstaged = (int)((unsigned)tot_packed >> 16);
+    // the word that holds rank t of the packed prefix (hi: staged, else active) and the rank inside it; wave-uniform
+    auto find_word = [&](int t, bool hi, int &n) -> int {
+        int kk = -1;
+        n = 0;
+        for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
+            const int k = k0 + lane;
+            const unsigned pa = k < nwords ? s_pre[k] : 0u, pb = k + 1 < nwords ? s_pre[k + 1] : (unsigned)tot_packed;
+            const int lo = (int)(hi ? pa >> 16 : pa & 0xffffu), up = (int)(hi ? pb >> 16 : pb & 0xffffu);
+            const u64 hit = __builtin_amdgcn_ballot_w64(k < nwords && lo <= t && t < up);
+            if (hit) {
+                const int src = __ffsll((unsigned long long)hit) - 1;
+                kk = k0 + src;
+                n = t - __builtin_amdgcn_readlane(lo, src);
+                break;
+            }
+        }
+        return kk;
+    };
+    auto nth_bit = [&](u64 word, int n) -> int {         // position of the n-th set bit (lane j looks at bit j)
+        const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
+        return __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(me)) - 1;
+    };
+    // active blocks before the staged block of rank t (all of them if there is no such block)
+    auto act_before_staged = [&](int t) -> int {
+        if (t >= nstaged) return nact;
+        int n;
+        const int k = find_word(t, true, n);
+        if (k < 0) return nact;
+        const int bpos = nth_bit(sb_uniform64(stage_word(k)), n);
+        const u64 a = sb_uniform64(s_bits[k]);
+        return (int)(__builtin_amdgcn_readfirstlane((int)s_pre[k]) & 0xffff) + __popcll(a & ((1ull << bpos) - 1ull));
+    };
+    const int r_begin = act_before_staged((int)(((long long)blockIdx.x * nstaged) / G));
+    const int r_end = act_before_staged((int)(((long long)(blockIdx.x + 1) * nstaged) / G));
+    // (the position of the active block of rank r: find_word(r, false, n), then nth_bit -- used by the rounds below,
+    // which re-make s_pre if a second round has to run over the cell lists' memory)
+    SB_T(12);                                            // prefix, share
 
     const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
     ThcBufs<FLY> B;
-    B.th = sb_make_rsrc(FLY ? (const void *)job.theta : (const void *)job.t0, fbytes);
-    B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.t0, fbytes);
-    B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.t0, fbytes);
+    B.th = sb_make_rsrc((const void *)job.theta, fbytes);                  // (theta is the t0 plane unless FLY)
+    B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.theta, fbytes);
+    B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.theta, fbytes);
     B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
     const bool fastx = g.nx > W + 2;                   // one conditional add wraps every column of a staged row
     const bool limited = g.bnd == BND_HALO;
 
-    // loads of row wv of the block at position pos
+    // the lane's column of the strip the loads are issued for: byte offsets in a field row and in a row of the
+    // land-side plane, bit in the 32-bit word (-1: no such cell); recomputed when the strip changes
+    int cc_strip = -1, cc_sh = -1;
+    unsigned cc_colb = 0, cc_clsb = 0;
+
+    // loads of row wv of block jp of `strip`
     // (always four loads, also behind the end of the schedule and for a drain step, from clamped addresses: the
     // compiler counts the loads in flight per program point, and a path without them would make it drain the queue)
     auto issue = [&](StripRegs<T, FLY> &R, unsigned sj) __attribute__((always_inline)) {
         const int strip = (int)(sj >> 16), jp = (int)(sj & 0xffffu);
-        const int ys = (jp - 1) * C + wv;               // interior row (may lie outside the grid: clamped or absent)
-        const int xs = strip * SW - H + lane;
-        bool ok = true;
-        int Xc = 0;
-        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = Xc >= 0 && Xc < g.nxh; }
-        else if (fastx) {
-            if (g.bnd == BND_WRAPPER) {
-                int m = xs + 1;
-                m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
-                Xc = (m < 1 ? 1 : m) - 1;
-            } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
-        } else {
-            int Yd;
-            sb_map_cell(g, xs, 0, Xc, Yd);
+        if (strip != cc_strip) {                         // wave-uniform
+            cc_strip = strip;
+            const int xs = strip * SW - H + lane;
+            bool ok = true;
+            int Xc = 0;
+            if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = Xc >= 0 && Xc < g.nxh; }
+            else if (fastx) {
+                if (g.bnd == BND_WRAPPER) {
+                    int m = xs + 1;
+                    m = m < 0 ? m + g.nx : (m >= g.nx ? m - g.nx : m);
+                    Xc = (m < 1 ? 1 : m) - 1;
+                } else Xc = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);
+            } else {
+                int Yd;
+                sb_map_cell(g, xs, 0, Xc, Yd);
+            }
+            const unsigned xc = ok ? (unsigned)Xc : 0u;  // every load is unconditional, from a clamped address
+            cc_colb = xc * (unsigned)sizeof(T);
+            cc_clsb = (xc >> 5) * 4u;
+            cc_sh = ok ? (int)(xc & 31u) : -1;
         }
+        const int ys = (jp - 1) * C + wv;               // interior row (may lie outside the grid: clamped or absent)
         int Yr;
         bool rowok = true;
         if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-        const unsigned xc = ok ? (unsigned)Xc : 0u;     // every load is unconditional, from a clamped address
-        const unsigned colb = xc * (unsigned)sizeof(T), clsb = (xc >> 5) * 4u;
-#if defined(STRIP_EXP) && (STRIP_EXP & 1)
-        Yr = wv;                                         // experiment: every block reads the same 16 rows (cache hits)
-#endif
         const unsigned rowb = (unsigned)Yr * (unsigned)g.nxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
-        R.th = sb_buf_ld<T>(B.th, colb, rowb);
-        if constexpr (FLY) { R.zz = sb_buf_ld<T>(B.zz, colb, rowb); R.sg = sb_buf_ld<T>(B.sg, colb, rowb); }
-        R.lw = __builtin_amdgcn_raw_buffer_load_b32(B.cls, clsb, wordb, 0);
-        R.sh = (ok && rowok) ? (int)(xc & 31u) : -1;
+        R.th = sb_buf_ld<T>(B.th, cc_colb, rowb);
+        if constexpr (FLY) { R.zz = sb_buf_ld<T>(B.zz, cc_colb, rowb); R.sg = sb_buf_ld<T>(B.sg, cc_colb, rowb); }
+        R.lw = __builtin_amdgcn_raw_buffer_load_b32(B.cls, cc_clsb, wordb, 0);
+        R.sh = rowok ? cc_sh : -1;
     };
 
-    // running column totals of the table this wave sums along latitude (waves 0, 1: 64 bit; wave 2: the count)
+    // running column totals of the table this wave sums along latitude (waves 8, 9: 64 bit; wave 10: the count)
     u64 carry = 0;
 
     // S1: the row's registers -> ring row (prefix along longitude only)
     auto stage = [&](StripRegs<T, FLY> &R, unsigned ent, int jp) __attribute__((always_inline)) {
+        sb_cdp kt = (sb_cdp)sb_strip_k;
+        asm volatile("" : "+s"(kt));                      // (opaque: the constants are loaded here, every time)
         const bool ok = R.sh >= 0;
         const bool land = ok && ((R.lw >> (R.sh & 31)) & 1u);
         T t0v = R.th;
         if constexpr (FLY) {
             // the sigmoid only where a lane of the wave stands on land (z == 0 -> t0 = theta exactly)   ref :166-167
-#if !(defined(STRIP_EXP) && (STRIP_EXP & 2))
-            if (__ballot(ok && R.zz != T(0)) != 0) t0v = sb_t0<T>(R.th, R.zz, R.sg, sd, rr);
-#else
-            t0v = R.th + R.zz * R.sg;                    // experiment: no sigmoid
-#endif
+            if (__builtin_amdgcn_ballot_w64(ok && R.zz != T(0)) != 0) t0v = strip_t0(R.th, R.zz, R.sg, sd, rr, kt);
         }
-        u64 qa = ok ? sb_to_fixed((double)t0v) : 0ull;
+        u64 qa = ok ? sb_to_fixed((double)t0v, kt) : 0ull;
         u64 ql = land ? qa : 0ull;
-        const u64 lm = __ballot(land);
+        const u64 lm = __builtin_amdgcn_ballot_w64(land);
         sb_scan2_u64(qa, ql);
         const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u)) + (land ? 1u : 0u);
-        const int slot = (jp * C + wv) & (STRIP_RING - 1);
-        const int o = slot * P + lane + 1;
+        const unsigned slot = (unsigned)(jp * C + wv) & RM;
+        const unsigned o = __umul24(slot, P) + lane + 1;
         sA[o] = qa;
         sL[o] = ql;
         sC[o] = (unsigned short)cnt;
@@ -304,44 +420,46 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         if (ent & SCH_RESTART) {
             // the tables start afresh: the row above the first one reads as zero, the running totals start at zero
             if (wv == NWV - 1) {
-                const int z = ((jp * C - 1) & (STRIP_RING - 1)) * P + lane + 1;
+                const unsigned z = __umul24((unsigned)(jp * C - 1) & RM, P) + lane + 1;
                 sA[z] = 0; sL[z] = 0; sC[z] = 0;
             }
             carry = 0;
         }
     };
 
-    // S2, waves 0-2: prefix along latitude of the 16 rows of the block at ring position jp
+    // S2, waves 8-10: prefix along latitude of the 16 rows of the block at ring position jp
     auto vertical = [&](int jp) __attribute__((always_inline)) {
-        if (wv < 2) {
-            u64 *tab = wv == 0 ? sA : sL;
+        const unsigned r0 = (unsigned)(jp * C) & RM;     // a block never straddles the end of the ring (128 = 8 x 16)
+        const unsigned o = __umul24(r0, P) + lane + 1;
+        if (wv < 10) {
+            u64 *tab = (wv == 8 ? sA : sL) + o;
 #pragma unroll
             for (int h0 = 0; h0 < C; h0 += 8) {          // eight rows of reads in flight
                 u64 v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = tab[((jp * C + h0 + i) & (STRIP_RING - 1)) * P + lane + 1];
+                for (int i = 0; i < 8; ++i) v[i] = tab[(h0 + i) * P];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { carry += v[i]; tab[((jp * C + h0 + i) & (STRIP_RING - 1)) * P + lane + 1] = carry; }
+                for (int i = 0; i < 8; ++i) { carry += v[i]; tab[(h0 + i) * P] = carry; }
             }
         } else {
+            unsigned short *tab = sC + o;
             unsigned v[C];
 #pragma unroll
-            for (int i = 0; i < C; ++i) v[i] = sC[((jp * C + i) & (STRIP_RING - 1)) * P + lane + 1];
+            for (int i = 0; i < C; ++i) v[i] = tab[i * P];
             unsigned cc = (unsigned)carry;
 #pragma unroll
-            for (int i = 0; i < C; ++i) { cc += v[i]; sC[((jp * C + i) & (STRIP_RING - 1)) * P + lane + 1] = (unsigned short)cc; }
+            for (int i = 0; i < C; ++i) { cc += v[i]; tab[i * P] = (unsigned short)cc; }
             carry = cc;
         }
     };
 
-    // The band bits of the two rows this wave queries in block jp of `strip`, as SCALAR loads (constant address
-    // space: the plane is k_scan's, read-only here).  Scalar loads count in lgkmcnt, which the step's barrier waits
-    // for anyway; a vector load here would sit in the in-order vmcnt queue between the prefetched blocks, and the
-    // wait for it would drain every load issued before it.
+    // The band bits of the two rows this wave lists in block jp of `strip`, as SCALAR loads (constant address space: the
+    // plane is k_scan's, read-only here).  Scalar loads count in lgkmcnt, not in the in-order vmcnt queue of the
+    // prefetched blocks: a vector load here would sit between them, and the wait for it would drain every load
+    // issued before it.
     struct BandWords { u64 a0, b0, a1, b1, c0, c1; int sh; };   // c: land-side word of the last longitude (f2py rule)
-    typedef const __attribute__((address_space(4))) u64 *cu64p;
     auto band_issue = [&](int strip, int jp) __attribute__((always_inline)) -> BandWords {
-        const int k = min(max(wv - 3, 0), C / 2 - 1);
+        const int k = min(wv, C / 2 - 1);
         const int y0 = (jp - 1) * C + 2 * k;
         const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
         const int xa = strip * SW + g.h;                 // array column of the strip's first owned cell
@@ -352,7 +470,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         w.a1 = bits[(size_t)(yb + g.h) * g.nw + wlo]; w.b1 = bits[(size_t)(yb + g.h) * g.nw + whi];
         w.sh = xa & 63;
         w.c0 = w.c1 = 0;
-        if (g.bnd == BND_WRAPPER && strip == job.thc_ntx - 1) {  // uniform; the strip that owns longitude nx
+        if (g.bnd == BND_WRAPPER && strip == job.ntx - 1) {      // uniform; the strip that owns longitude nx
             cu64p cls = (cu64p)job.clsbits;
             const int wl = (g.nx - 1 + g.h) >> 6;
             w.c0 = cls[(size_t)(ya + g.h) * g.nw + wl]; w.c1 = cls[(size_t)(yb + g.h) * g.nw + wl];
@@ -360,9 +478,11 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         return w;
     };
 
-    // S2, waves 3-10: the band cells of two rows of the block at position qpos
-    auto query = [&](int qpos, int strip, int jp, const BandWords &bwd, bool qdo) __attribute__((always_inline)) {
-        const int lx = lane & (SW - 1), ly = 2 * min(max(wv - 3, 0), C / 2 - 1) + (lane >> 5);
+    // S1, waves 0-7: the band cells of two rows of the queried block -> the step's compact list.  A cell's code is
+    // row << 5 | column, plus (f2py rule, last longitude only) bit 10 and in bit 9 its own land-side bit -- see `query`.
+    // The waves reserve their entries with one LDS atomic each: the order of the list is of no consequence.
+    auto list_cells = [&](int strip, int jp, const BandWords &bwd, int buf) __attribute__((always_inline)) {
+        const int lx = lane & (SW - 1), ly = 2 * min(wv, C / 2 - 1) + (lane >> 5);
         const int x = strip * SW + lx, y = (jp - 1) * C + ly;
         // (the four words are scalars: shift each by the lane's amount, then select -- a select between the words
         // themselves makes the compiler index them in scratch memory)
@@ -370,28 +490,46 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         const unsigned sa = (unsigned)(bp & 63);
         const unsigned bit0 = (unsigned)((bp < 64 ? bwd.a0 >> sa : bwd.b0 >> sa) & 1ull);
         const unsigned bit1 = (unsigned)((bp < 64 ? bwd.a1 >> sa : bwd.b1 >> sa) & 1ull);
-        const bool bit = ((lane >> 5) ? bit1 : bit0) != 0u;
-        const bool isband = qdo && x < g.nx && y >= 0 && y < g.rows && bit;
-        if (__ballot(isband) == 0) return;              // wave-uniform
-        const size_t o = (size_t)(isband ? y : 0) * g.nx + (isband ? x : 0);
-        SbCellState<T> cst = SbCellState<T>{T(0), T(0), T(0), T(0)};
-        if constexpr (!WF) { if (isband) cst = sb_trigger_load<T>(job, o); }
+        const bool isband = x < g.nx && y >= 0 && y < g.rows && ((lane >> 5) ? bit1 : bit0) != 0u;
+        const u64 m = __builtin_amdgcn_ballot_w64(isband);
+        if (m == 0) return;                              // wave-uniform
+        unsigned code = (unsigned)(ly << 5 | lx);
+        if (g.bnd == BND_WRAPPER && x == g.nx - 1) {
+            const unsigned sl = (unsigned)((g.nx - 1 + g.h) & 63);
+            code |= 1u << 10 | (unsigned)(((lane >> 5) ? (bwd.c1 >> sl) : (bwd.c0 >> sl)) & 1ull) << 9;
+        }
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_misc[1 + buf], __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned at = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (isband) s_cell[buf][at] = (unsigned short)code;
+    };
+
+    // S2, waves 0 ..: 64 entries of the list per wave: bisection for the radius, contrast, result
+    auto query = [&](int qpos, int strip, int jp, int buf) __attribute__((always_inline)) {
+        const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
+        const int e = wv * SB_WAVE + lane;
+        if (wv * SB_WAVE >= ncell) return;               // wave-uniform
+        const bool valid = e < ncell;
+        const unsigned code = s_cell[buf][valid ? e : 0];
+        const int lx = (int)(code & 31u), ly = (int)((code >> 5) & 15u);
+        const int x = strip * SW + lx, y = (jp - 1) * C + ly;
+        const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;     // (fewer than 2^31 cells: check_dims)
         int lim = H;
-        if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));
+        if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));   // uniform branch
         const int limc = max(lim, 1);
-        const int rho = jp * C + ly;                     // ring row of the cell
-        const int cx = lx + H + 1;                       // its table column
+        const unsigned rho = (unsigned)(jp * C + ly);    // ring row of the cell
+        const unsigned cx = (unsigned)(lx + H + 1);      // its table column
         // land-side count of the square of radius rad: C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0),
         // r0 = rho-rad-1, r1 = rho+rad, a0 = cx-rad-1, a1 = cx+rad
         auto count = [&](int rad) __attribute__((always_inline)) {
-            const int r1 = ((rho + rad) & (STRIP_RING - 1)) * P, r0 = ((rho - rad - 1) & (STRIP_RING - 1)) * P;
-            const int a1 = cx + rad, a0 = cx - rad - 1;
-            return (int)(unsigned short)((unsigned)sC[r1 + a1] - (unsigned)sC[r0 + a1] - (unsigned)sC[r1 + a0] + (unsigned)sC[r0 + a0]);
+            const unsigned r1 = __umul24((rho + rad) & RM, P) + cx, r0 = __umul24((rho - rad - 1) & RM, P) + cx;
+            return (int)(unsigned short)((unsigned)sC[r1 + rad] - (unsigned)sC[r0 + rad] - (unsigned)sC[r1 - rad - 1] + (unsigned)sC[r0 - rad - 1]);
         };
         // the widest square, then a branch-free bisection (1 + log2 H probes of 4 reads)
         int nl = count(limc);
         const bool got = nl > 0 && nl < (2 * limc + 1) * (2 * limc + 1);
-        const bool found = isband && lim >= 1 && got;
+        const bool found = valid && lim >= 1 && got;
         int lo = got ? 1 : limc, hi = limc;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -403,58 +541,55 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
             lo = (act && !okm) ? mid + 1 : lo;
         }
         const int nn = hi, area = (2 * nn + 1) * (2 * nn + 1);
-        const int r1 = ((rho + nn) & (STRIP_RING - 1)) * P, r0 = ((rho - nn - 1) & (STRIP_RING - 1)) * P;
-        const int a1 = cx + nn, a0 = cx - nn - 1;
-        const u64 l11 = sL[r1 + a1], l01 = sL[r0 + a1], l10 = sL[r1 + a0], l00 = sL[r0 + a0];
-        const u64 q11 = sA[r1 + a1], q01 = sA[r0 + a1], q10 = sA[r1 + a0], q00 = sA[r0 + a0];
-        const u64 ownw = s_land[rho & (STRIP_RING - 1)];
+        const unsigned r1 = __umul24((rho + nn) & RM, P) + cx, r0 = __umul24((rho - nn - 1) & RM, P) + cx;
+        const u64 l11 = sL[r1 + nn], l01 = sL[r0 + nn], l10 = sL[r1 - nn - 1], l00 = sL[r0 - nn - 1];
+        const u64 q11 = sA[r1 + nn], q01 = sA[r0 + nn], q10 = sA[r1 - nn - 1], q00 = sA[r0 - nn - 1];
+        const u64 ownw = s_land[rho & RM];
         const long long RL = (long long)((l11 - l01) - (l10 - l00));      // exact: the tables wrap, the window sum does not
-        const long long RA = (long long)((q11 - q01) - (q10 - q00));
-        // the two means by reciprocals of the (small, exact) counts: within an ulp of the quotients
-        const double ml = (double)RL * sb_inv((double)nl), ms = (double)(RA - RL) * sb_inv((double)(area - nl));
-        const T contrast = (T)((ml - ms) * 0x1p-40);
-        // the cell's own class: the table's centre, except that the f2py boundary rule maps the centre of the
-        // window at the last longitude to column 1   ref :182-186, seabreeze_diag_python.f90:202
-        // (there the cell's own land-side bit comes from the plane itself: scalar words, loaded with the band words)
-        bool own = (ownw >> (lx + H)) & 1ull;
-        if (g.bnd == BND_WRAPPER && x == g.nx - 1) {
-            const unsigned sl = (unsigned)((g.nx - 1 + g.h) & 63);
-            own = ((lane >> 5) ? (bwd.c1 >> sl) : (bwd.c0 >> sl)) & 1ull;
-        }
+        const long long RS = (long long)((q11 - q01) - (q10 - q00)) - RL; // sea side
+        // land mean - sea mean = (RL ns - RS nl) / (nl ns): one reciprocal of an exact small integer (v_rcp_f64 + two
+        // Newton steps: within an ulp of the quotient)
+        auto to_f64 = [](long long v) { return __builtin_fma((double)(int)(v >> 32), 0x1p32, (double)(unsigned)v); };
+        const double dnl = (double)nl, dns = (double)(area - nl);
+        const double num = to_f64(RL) * dns - to_f64(RS) * dnl;
+        const T contrast = (T)(num * sb_inv(dnl * dns) * 0x1p-40);
+        // the cell's own class: the table's centre, except that the f2py boundary rule maps the centre of the window at
+        // the last longitude to column 1 (there the list entry carries the bit)   ref :182-186, seabreeze_diag_python.f90:202
+        const bool own = (code >> 10) & 1u ? ((code >> 9) & 1u) != 0u : ((ownw >> (lx + H)) & 1ull) != 0ull;
         const T mul = own ? T(1) : T(-1);
         int nnmax = 0;
-        if (found) {
-            nnmax = nn;
-            if constexpr (WF) job.thc[o] = mul * contrast;                   // ref :216; k_wind applies :235-266
-            else sb_trigger_update<T>(job, o, mul * contrast, cst);           // ref :216, :235-266
-        }
-        // cells whose window outgrows the tables (none on a grid whose distance field was made with a window of
-        // at most 15 cells): global-memory path
-        if (__ballot(isband && !found) != 0) {
-            if (isband && !found) {
-                int cap = g.nx + g.ny;
-                if (limited) cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
-                bool one_class;
-                int nng;
-                const T cg = contrast_global(job, x, y, cap, sd, rr, nng, one_class);
-                atomicAdd(&job.counters[0], 1);
-                if (one_class) atomicAdd(&job.counters[1], 1);
-                nnmax = nng;
-                const T mulg = sb_bit(job.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
-                if constexpr (WF) job.thc[o] = mulg * cg;
-                else sb_trigger_update<T>(job, o, mulg * cg, cst);
+        if constexpr (WF) {
+            if (found) { nnmax = nn; job.thc[o] = mul * contrast; }          // ref :216; k_wind applies :235-266
+        } else {
+            if (found) {
+                nnmax = nn;
+                const DiagJob<T> &cj = *(const DiagJob<T> *)job.cold;
+                sb_trigger_update<T>(cj, (size_t)o, mul * contrast, sb_trigger_load<T>(cj, (size_t)o));     // ref :216, :235-266
             }
         }
+        // cells whose window outgrows the tables: marked, handled behind the march
+        if (valid && !found) { job.thc[o] = strip_mark<T>(); s_misc[4] = 1; }
         // per-block largest radius (diagnostic, read by sb_last_counters); the flag k_scan raised is 1
         nnmax = sb_wave_max_to_last(nnmax);
-        if (lane == SB_WAVE - 1 && nnmax > 1) atomicMax(&job.tile_nnmax[qpos], nnmax);
+        if (lane == SB_WAVE - 1 && nnmax > 1) atomicMax(&job.flags[qpos], nnmax);
     };
 
     SB_T(0);                                             // prologue
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
     for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
         const int rb = min(ra + STRIP_ROUND, r_end);
-        const int p0 = strip_pick(s_bits, nwords, ra, lane), p1 = strip_pick(s_bits, nwords, rb - 1, lane);
+        if (ra > r_begin) {                              // (a further round: the prefix array was overwritten by cell lists)
+            unsigned v = 0;
+            if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
+            int tp;
+            const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tp);
+            if (tid < nwords) s_pre[tid] = (unsigned)ex;
+            __syncthreads();
+        }
+        int n0, n1;
+        const int k0w = find_word(ra, false, n0), k1w = find_word(rb - 1, false, n1);
+        const int p0 = k0w < 0 ? -1 : k0w * 64 + nth_bit(sb_uniform64(s_bits[k0w < 0 ? 0 : k0w]), n0);
+        const int p1 = k1w < 0 ? -1 : k1w * 64 + nth_bit(sb_uniform64(s_bits[k1w < 0 ? 0 : k1w]), n1);
         if (p0 < 1 || p1 < p0) break;                    // (cannot happen: ranks below the count exist, position 0 is virtual)
         // -- the schedule: staged positions in ascending order with their flags, by wave 0 --
         // act = active blocks of this round; staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
@@ -462,7 +597,8 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
         if (wv == 0) {
             // (three warm-up steps lead the schedule: they stage nothing and only issue the loads of the first three
             // blocks, so that every load of the loop is issued at the same three program points -- see `step`)
-            if (lane < STRIP_DEPTH) { s_sched[lane] = SCH_DRAIN | SCH_IDLE; s_sjp[lane] = 0; }
+            if (lane < STRIP_DEPTH) s_ent[lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
+            if (lane < 3) s_misc[1 + lane] = 0;
             int n_out = STRIP_DEPTH;
             for (int kb = kw0 - 1; kb <= kw1 + 1; kb += SB_WAVE) {
                 const int k = kb + lane;
@@ -492,10 +628,10 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
                     unsigned e = (unsigned)pp;
                     e |= ((q2 >> b) & 1ull) ? SCH_Q2 : 0u;
                     e |= ((rs >> b) & 1ull) ? SCH_RESTART : 0u;
-                    if (at < STRIP_SCHED) { s_sched[at] = e; s_sjp[at] = sjv; }
+                    if (at < STRIP_SCHED) s_ent[at] = make_uint2(e, sjv);
                     ++at;
                     if ((en >> b) & 1ull) {
-                        if (at < STRIP_SCHED) { s_sched[at] = (unsigned)pp | SCH_DRAIN | (((q1 >> b) & 1ull) ? SCH_Q1 : 0u); s_sjp[at] = sjv; }
+                        if (at < STRIP_SCHED) s_ent[at] = make_uint2((unsigned)pp | SCH_DRAIN | (((q1 >> b) & 1ull) ? SCH_Q1 : 0u), sjv);
                         ++at;
                     }
                 }
@@ -504,48 +640,54 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
             // the compiler's count of the loads in flight collapses and it drains the queue every third step)
             n_out = min(n_out, STRIP_SCHED - 2);
             const int n_pad = (n_out + STRIP_DEPTH - 1) / STRIP_DEPTH * STRIP_DEPTH;
-            if (lane < n_pad - n_out) { s_sched[n_out + lane] = SCH_DRAIN | SCH_IDLE; s_sjp[n_out + lane] = 0; }
+            if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
             if (lane == 0) s_misc[0] = n_pad;
         }
         __syncthreads();
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
-        // (behind the end: the last entry's position again, as a drain step without a query -- its loads are dummies)
-        auto sched = [&](int i) -> unsigned { return i < nst ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_sched[i]) : SCH_DRAIN; };
-        auto sched_sj = [&](int i) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_sjp[i < nst ? i : nst - 1]); };
-
+        // a step's entry travels in scalar registers from the step that issues its block's loads (three steps ahead)
+        // to the step itself; behind the end of the schedule: idle steps
+        auto entry = [&](int i, unsigned &e, unsigned &j) __attribute__((always_inline)) {
+            const uint2 v = s_ent[i < nst ? i : nst - 1];
+            e = i < nst ? (unsigned)__builtin_amdgcn_readfirstlane((int)v.x) : (SCH_DRAIN | SCH_IDLE);
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y);
+        };
+        unsigned E0, J0, E1, J1, E2, J2;
+        entry(0, E0, J0); entry(1, E1, J1); entry(2, E2, J2);
         StripRegs<T, FLY> R0, R1, R2;
         R0.th = R1.th = R2.th = T(0); R0.zz = R1.zz = R2.zz = T(0); R0.sg = R1.sg = R2.sg = T(0);
         R0.lw = R1.lw = R2.lw = 0u; R0.sh = R1.sh = R2.sh = -1;
         SB_T(1);                                         // pick, schedule
-        // A step: S1 of block i, barrier, S2 (sums along latitude || queries of the block two up); a drain step
-        // (behind the last block of a run) has no S1 and queries the block one up.  The three register sets take
-        // turns -- as three copies of the step in the loop body, not as a switch or an inner loop: the compiler counts
-        // the loads in flight per program point, and only straight-line rotation with the same loads on every path
-        // lets it wait for block i's loads alone while those of blocks i + 1 and i + 2 stay in flight.  The set just
-        // consumed receives the loads of block i + 3.
-        auto step = [&](StripRegs<T, FLY> &R, int i) __attribute__((always_inline)) {
-            const unsigned ent = sched(i), sj = sched_sj(i);
+        // A step: S1 of block i (and the list of the band cells to query), barrier, S2 (sums along latitude || queries
+        // of the block two up); a drain step (behind the last block of a run) has no block and queries the block one
+        // up.  The three register sets take turns -- as three copies of the step in the loop body, not as a switch, an
+        // inner loop or a loop with an early exit: the compiler counts the loads in flight per program point, and only
+        // straight-line rotation with the same loads on every path lets it wait for block i's loads alone while those
+        // of blocks i + 1 and i + 2 stay in flight.  The set just consumed receives the loads of block i + 3.
+        auto step = [&](StripRegs<T, FLY> &R, unsigned &E, unsigned &J, int i, int buf) __attribute__((always_inline)) {
+            const unsigned ent = E, sj = J;
+            entry(i + STRIP_DEPTH, E, J);                // (consumed by `issue` below: the read travels under S1)
             const int pos = (int)(ent & 0xffffu);
             const int strip = (int)(sj >> 16), jp = (int)(sj & 0xffffu);
             const bool drain = (ent & SCH_DRAIN) != 0, idle = (ent & SCH_IDLE) != 0;
             const int qoff = drain ? 1 : 2;
-            const bool qdo = wv >= 3 && wv < 3 + C / 2 && (ent & (drain ? SCH_Q1 : SCH_Q2));
-            BandWords bwd;
-            bwd.a0 = bwd.b0 = bwd.a1 = bwd.b1 = bwd.c0 = bwd.c1 = 0; bwd.sh = 0;
+            const bool qany = (ent & (drain ? SCH_Q1 : SCH_Q2)) != 0;
             if (!idle) {
                 if (ent & SCH_RESTART) lds_barrier();             // the queries of the run before have left the ring
-                bwd = band_issue(strip, jp - qoff);
+                BandWords bwd;
+                const bool lister = qany && wv < C / 2;
+                if (lister) bwd = band_issue(strip, jp - qoff);
+                if (tid == STRIP_NT - 1) s_misc[1 + (buf == 2 ? 0 : buf + 1)] = 0;   // the next step's list starts empty
                 if (!drain) stage(R, ent, jp);
+                if (lister) list_cells(strip, jp - qoff, bwd, buf);
             }
-            issue(R, sched_sj(i + STRIP_DEPTH));                  // (the one place of this copy of the step that loads)
+            issue(R, J);                                          // (the one place of this copy of the step that loads)
             SB_T(2);                                     // S1 (incl. the wait for the block's loads)
             if (!idle) {
                 lds_barrier();
                 SB_T(3);                                 // barrier
-                if (!drain && wv < 3) vertical(jp);
-#if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
-                else query(pos - qoff, strip, jp - qoff, bwd, qdo);
-#endif
+                if (wv >= 8) { if (!drain && wv < 11) vertical(jp); }
+                else if (qany) query(pos - qoff, strip, jp - qoff, buf);
                 SB_T(4);                                 // S2
 #ifdef SB_STAMPS
                 acc[drain ? 5 : 6] += 1;
@@ -553,14 +695,53 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
             }
         };
         for (int i = 0; i < nst; i += STRIP_DEPTH) {         // nst is a multiple of three
-            step(R0, i);
-            step(R1, i + 1);
-            step(R2, i + 2);
+            step(R0, E0, J0, i, 0);
+            step(R1, E1, J1, i + 1, 1);
+            step(R2, E2, J2, i + 2, 2);
         }
         __syncthreads();                                 // the schedule and the ring are free for the next round
     }
 
     SB_T(7);                                             // round tail
+    // ---- the marked cells (rare): every band cell of this workgroup's blocks that holds the mark takes the
+    // global-memory search; everything it needs comes from the job's copy in device memory ----
+    if (s_misc[4] != 0) {                                // (uniform: read behind the round's last barrier)
+        const DiagJob<T> &cj = *job.cold;
+        {                                                // the prefix array again (the cell lists lay over it)
+            unsigned v = 0;
+            if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
+            int tp;
+            const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tp);
+            if (tid < nwords) s_pre[tid] = (unsigned)ex;
+            __syncthreads();
+        }
+        for (int r = r_begin; r < r_end; ++r) {
+            int n;
+            const int kw = find_word(r, false, n);
+            if (kw < 0) break;
+            const int pos = kw * 64 + nth_bit(sb_uniform64(s_bits[kw]), n);
+            const int strip = pos / npad, jp = pos - strip * npad;
+            int nnmax = 0;
+            if (tid < SW * C) {
+                const int x = strip * SW + (tid & (SW - 1)), y = (jp - 1) * C + (tid >> 5);
+                if (x < g.nx && y >= 0 && y < g.rows && sb_bit(job.bandbits, g.nw, x + g.h, y + g.h)) {
+                    const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;
+                    if (strip_is_mark(job.thc[o])) {
+                        int cap = g.nx + g.ny;
+                        if (limited) cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
+                        bool one_class;
+                        const T cg = contrast_global(cj, x, y, cap, sd, rr, nnmax, one_class);
+                        atomicAdd(&cj.counters[0], 1);
+                        if (one_class) atomicAdd(&cj.counters[1], 1);
+                        const T mulg = sb_bit(cj.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
+                        if constexpr (WF) job.thc[o] = mulg * cg;
+                        else sb_trigger_update<T>(cj, (size_t)o, mulg * cg, sb_trigger_load<T>(cj, (size_t)o));
+                    }
+                }
+            }
+            if (nnmax > 1) atomicMax(&job.flags[pos], nnmax);
+        }
+    }
     if (job.fold) {
         // ---- k_wind's segment lists (k_prep's work on single-domain host-model calls): sub-list `part` holds the
         // segments with band cells of its contiguous range of the band plane, in ascending order ----
@@ -595,13 +776,34 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(const T *__restrict__ stats,
 #endif
 }
 
+// the hot part of the job, by value; everything else the kernel reads -- rarely -- from the copy of the whole job that
+// k_scan leaves in device memory (job.self)
+template <typename T>
+static StripJob<T> strip_job(const DiagJob<T> &job) {
+    StripJob<T> s;
+    s.g = job.g;
+    s.theta = job.t0_fly ? job.theta : job.t0; s.z = job.z; s.sigma = job.sigma;
+    s.clsbits = job.clsbits; s.bandbits = job.bandbits;
+    s.thc = job.thc;
+    s.flags = job.tile_nnmax;
+    s.ntx = job.thc_ntx; s.nty = job.thc_nty;
+    s.fold = job.fold; s.fold_nparts = job.fold_nparts; s.ngath = job.ngath; s.seg_cap = job.seg_cap;
+    s.stats = job.stats; s.stats_out = job.stats_out;
+    s.fold_partials = job.fold_partials; s.gath = job.gath;
+    s.seg_list = job.seg_list; s.seg_count = job.seg_count;
+    s.cold = job.self;
+    s.stamps = job.stamps;
+    return s;
+}
+
 template <typename T>
 hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st) {
     const dim3 gr(ncu), bl(STRIP_NT);                   // one persistent workgroup per CU
-    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_strip<T, true, true>), gr, bl, 0, st, job.stats, ncu, job);
-    else if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true, false>), gr, bl, 0, st, job.stats, ncu, job);
-    else if (job.wind_final) hipLaunchKernelGGL((k_strip<T, false, true>), gr, bl, 0, st, job.stats, ncu, job);
-    else hipLaunchKernelGGL((k_strip<T, false, false>), gr, bl, 0, st, job.stats, ncu, job);
+    const StripJob<T> sj = strip_job<T>(job);
+    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_strip<T, true, true>), gr, bl, 0, st, ncu, sj);
+    else if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true, false>), gr, bl, 0, st, ncu, sj);
+    else if (job.wind_final) hipLaunchKernelGGL((k_strip<T, false, true>), gr, bl, 0, st, ncu, sj);
+    else hipLaunchKernelGGL((k_strip<T, false, false>), gr, bl, 0, st, ncu, sj);
     return hipGetLastError();
 }
 template hipError_t sb_launch_strip<float>(const DiagJob<float> &, int, hipStream_t);
@@ -611,5 +813,5 @@ template hipError_t sb_launch_strip<double>(const DiagJob<double> &, int, hipStr
 bool sb_strip_shape(int nx, int rows, int *ntx, int *nty) {
     *ntx = (nx + STRIP_SW - 1) / STRIP_SW;
     *nty = (rows + STRIP_C - 1) / STRIP_C;
-    return (long long)*ntx * (*nty + 2) <= 65535;
+    return (long long)*ntx * (*nty + 2) < (long long)STRIP_MAXW * 64;
 }

@@ -338,25 +338,23 @@ def test_um_layout_halo2_240_steps(hipctx, oracles):
 
 
 def test_search_radius_beyond_lds_halo(hipctx, oracles):
-    """Radius hint 8 but radii up to ~13: cells past the LDS halo take the global-memory path
-    and must give the same numbers."""
+    """Radii beyond the 16 cells the strip kernel's tables hold (a distance field made with a 20-cell window, radius
+    hint left at 16): the cells past the LDS halo are marked during the march, take the global-memory search behind
+    it and must give the same numbers."""
     nx, ny, nz = 256, 192, 2
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)
     coast = orc.get_edges(st.landfrac, st.icefrac)
-    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=5000.0, kwin=12)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=5000.0, kwin=20)
     p = synth.pressure_1d(nz, dt)
     th = synth.theta_step(st, 1, dt)
     u, v = synth.wind_step(st, nz, 1, dt)
     so, sh = _states(ny, nx, dt, 3), _states(ny, nx, dt, 3)
     oo = orc.diag(1, p, st.z, st.sigma, th, v, u, cdist, *so, maxdist=5000.0)
-    hipctx.set_search_radius_hint(8)
-    try:
-        oh = hipctx.diag(1, p, st.z, st.sigma, th, v, u, cdist, *sh, maxdist=5000.0)
-        c = hipctx.last_counters()
-    finally:
-        hipctx.set_search_radius_hint(16)
-    assert orc.last_nn_max > 8 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
+    hipctx.set_search_radius_hint(16)
+    oh = hipctx.diag(1, p, st.z, st.sigma, th, v, u, cdist, *sh, maxdist=5000.0)
+    c = hipctx.last_counters()
+    assert orc.last_nn_max > 16 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
     for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
         _assert_close64(oh[k, :-1], oo[k, :-1], nm)
     _assert_close64(sh[2], so[2], "thc")
@@ -368,23 +366,20 @@ def test_search_radius_beyond_lds_halo_generic(hipctx, oracles):
     dt, orc = np.float64, oracles[8]
     st = synth.static_fields(nx, ny, dt)
     coast = orc.get_edges(st.landfrac, st.icefrac)
-    # a fabricated distance field: every cell within 11 cells of the coast is "in the band"
-    # (the flavour's maxdist is fixed at 180 km), so interior band cells need radii up to 12
-    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=9000.0, kwin=11)
+    # a fabricated distance field: every cell within 19 cells of the coast is "in the band"
+    # (the flavour's maxdist is fixed at 180 km), so interior band cells need radii up to 20
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=9000.0, kwin=19)
     cdist = np.where(np.abs(cdist) < 12000.0, np.sign(cdist) * np.minimum(np.abs(cdist), 179.0), cdist)
     p = synth.pressure_3d(st, nz, dt)
     so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
-    hipctx.set_search_radius_hint(8)
-    try:
-        for tn in (1, 2):
-            th = synth.theta_step(st, tn, dt)
-            u, v = synth.wind_step(st, nz, tn, dt)
-            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
-            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
-        c = hipctx.last_counters()
-    finally:
-        hipctx.set_search_radius_hint(16)
-    assert orc.last_nn_max > 8 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
+    hipctx.set_search_radius_hint(16)
+    for tn in (1, 2):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1)
+        hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+    c = hipctx.last_counters()
+    assert orc.last_nn_max > 16 and c["global_path_cells"] > 0 and c["max_radius"] == orc.last_nn_max
     for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
         _assert_close64(a, b, nm)
 

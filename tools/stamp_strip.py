@@ -38,6 +38,7 @@ tot = s[:, [0, 1, 2, 3, 4, 7, 8]].sum(axis=1)
 for i in (0, 1, 2, 3, 4, 7, 8):
     print(f"  {names[i]:10s} thread 0: per workgroup mean {s[:, i].mean():9.0f} cyc ({100 * s[:, i].sum() / tot.sum():4.1f} %)"
           + (f"   per pass {s[:, i].sum() / max(1, (steps + drains).sum()):7.0f}" if i in (2, 3, 4) else ""))
+print(f"  prologue split: flags/plane/statistics {s[:, 11].mean():.0f}, prefix + share {s[:, 12].mean():.0f}, rest {(s[:, 0] - s[:, 11] - s[:, 12]).mean():.0f}")
 print(f"  total cycles per workgroup mean {tot.mean():.0f} max {tot.max()}; wall (10 ns ticks): start spread "
       f"{s[:, 9].max() - s[:, 9].min()}, life mean {np.mean(s[:, 10] - s[:, 9]):.0f} max {np.max(s[:, 10] - s[:, 9])}, "
       f"kernel span {s[:, 10].max() - s[:, 9].min()}")
