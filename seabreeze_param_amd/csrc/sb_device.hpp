@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define SB_WAVE 64
-#define SB_NSTAMP 16                 // diagnostic build: clock sums per k_thc3 workgroup
+#define SB_NSTAMP 32                 // diagnostic build: clock sums per k_thc3 workgroup
 
 enum { SB_FLAVOUR_GENERIC = 0, SB_FLAVOUR_WRAPPER = 1 };
 enum { BND_WRAPPER = 0, BND_GLOBAL = 1, BND_HALO = 2 };

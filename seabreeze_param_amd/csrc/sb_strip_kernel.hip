@@ -53,6 +53,11 @@ typedef unsigned long long u64;
 #else
 #define SB_T(i) do { } while (0)
 #endif
+#ifdef SB_STAMPS_FINE             // (stamps inside S1: each costs the wave some 700 cycles -- shares only)
+#define SB_TF(i) SB_T(i)
+#else
+#define SB_TF(i) do { } while (0)
+#endif
 
 // The fp64 constants of a staged row -- the logistic's argument reduction and Taylor coefficients, the fixed-point
 // conversion -- live in constant memory and are fetched by scalar loads where they are used (two s_load_dwordx16 per
@@ -67,21 +72,30 @@ __constant__ double sb_strip_k[20] = {
     -1024.0, 1024.0, 0x1p40, 0x1.8p52,                                                               // 14..17: fixed point
     -0.0060956, 0.0};                                                                               // 18: gmma (ref :138)
 typedef const __attribute__((address_space(4))) double *sb_cdp;
+#ifndef STRIP_KTAB
+#define STRIP_KTAB 0              // 0: the constants as literals (measured faster by 1.6 us: the scalar loads stall the row);
+                                  // 1: by scalar loads from the table
+#endif
+#if STRIP_KTAB
+#define SB_K(i, lit) k[i]
+#else
+#define SB_K(i, lit) (lit)
+#endif
 
 // 1 / (1 + exp(y)): as sb_logistic_of_neg<double> (sb_device.hpp), constants from the table
 __device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
     y = fmin(fmax(y, -708.0), 700.0);                         // (literals: known not to be NaN, no canonicalisation)
-    const double n = __builtin_rint(y * k[0]);
-    double r = __builtin_fma(-n, k[1], y);
-    r = __builtin_fma(-n, k[2], r);                           // |r| <= ln2/2
+    const double n = __builtin_rint(y * SB_K(0, 1.4426950408889634));
+    double r = __builtin_fma(-n, SB_K(1, 0.6931471805599453), y);
+    r = __builtin_fma(-n, SB_K(2, 2.3190468138462996e-17), r);                           // |r| <= ln2/2
     // exp(r), degree 11, as E(r^2) + r O(r^2): two Horner chains of five, every multiply-add with ONE constant (a
     // scalar operand; a second one would have to be copied to vector registers first)
     const double r2 = r * r;
-    double e = __builtin_fma(r2, k[12], k[10]);               // 1/10!, 1/8!
-    double o = __builtin_fma(r2, k[13], k[11]);               // 1/11!, 1/9!
-    e = __builtin_fma(e, r2, k[8]);  o = __builtin_fma(o, r2, k[9]);      // 1/6!, 1/7!
-    e = __builtin_fma(e, r2, k[6]);  o = __builtin_fma(o, r2, k[7]);      // 1/4!, 1/5!
-    e = __builtin_fma(e, r2, 0.5);   o = __builtin_fma(o, r2, k[5]);      // 1/2!, 1/3!
+    double e = __builtin_fma(r2, SB_K(12, 2.755731922398589e-07), SB_K(10, 2.48015873015873e-05));               // 1/10!, 1/8!
+    double o = __builtin_fma(r2, SB_K(13, 2.505210838544172e-08), SB_K(11, 2.7557319223985893e-06));               // 1/11!, 1/9!
+    e = __builtin_fma(e, r2, SB_K(8, 1.388888888888889e-03));  o = __builtin_fma(o, r2, SB_K(9, 1.984126984126984e-04));      // 1/6!, 1/7!
+    e = __builtin_fma(e, r2, SB_K(6, 4.1666666666666664e-02));  o = __builtin_fma(o, r2, SB_K(7, 8.333333333333333e-03));      // 1/4!, 1/5!
+    e = __builtin_fma(e, r2, 0.5);   o = __builtin_fma(o, r2, SB_K(5, 1.6666666666666666e-01));      // 1/2!, 1/3!
     e = __builtin_fma(e, r2, 1.0);   o = __builtin_fma(o, r2, 1.0);
     const double p = __builtin_fma(o, r, e);
     const double x = 1.0 + ldexp(p, (int)n);
@@ -92,7 +106,7 @@ __device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
 // t0 = theta - (gmma*z)*sigmoid(sigma)   ref: generic/sea_breeze_diag.f90:166-167,478-480 (as sb_t0)
 __device__ __forceinline__ double strip_t0(double theta, double z, double sigma, double sd, double r, sb_cdp k) {
     if (z == 0.0) return theta;
-    return theta - ((k[18] * z) * strip_logistic_of_neg(-sd * (sigma - r), k));
+    return theta - ((SB_K(18, -0.0060956) * z) * strip_logistic_of_neg(-sd * (sigma - r), k));
 }
 __device__ __forceinline__ float strip_t0(float theta, float z, float sigma, float sd, float r, sb_cdp) {
     return sb_t0<float>(theta, z, sigma, sd, r);
@@ -101,7 +115,7 @@ __device__ __forceinline__ float strip_t0(float theta, float z, float sigma, flo
 // t0 (K) -> fixed point.  fma rounds x * 2^40 + 1.5 * 2^52 to an integer held in the mantissa (|x| <= 1024).
 __device__ __forceinline__ u64 sb_to_fixed(double x, sb_cdp k) {
     x = fmin(fmax(x, -1024.0), 1024.0);
-    const double y = __builtin_fma(x, k[16], k[17]);
+    const double y = __builtin_fma(x, SB_K(16, 0x1p40), SB_K(17, 0x1.8p52));
     return (u64)(__double_as_longlong(y) - 0x4338000000000000ll);
 }
 
@@ -128,6 +142,25 @@ __device__ __forceinline__ void sb_scan2_u64(u64 &a, u64 &b) {
 #undef SB_SCAN_STEP
     a = ((u64)ah << 32) | al;
     b = ((u64)bh << 32) | bl;
+}
+
+// ... of one 64-bit integer (rows that lie on one side of the coast: the land-side sums are all zero, or equal the
+// sums over all cells); the steps follow each other directly, so each is padded to the two wait states of a DPP read
+__device__ __forceinline__ void sb_scan1_u64(u64 &a) {
+    unsigned al = (unsigned)a, ah = (unsigned)(a >> 32);
+#define SB_SCAN_STEP1(ctl)                                         \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctl "\n\t"               \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctl "\n\ts_nop 0\n\t"
+    asm volatile("s_nop 1\n\t"
+                 SB_SCAN_STEP1("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP1("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP1("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP1("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 SB_SCAN_STEP1("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 SB_SCAN_STEP1("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(al), "+v"(ah)::"vcc");
+#undef SB_SCAN_STEP1
+    a = ((u64)ah << 32) | al;
 }
 
 __device__ __forceinline__ u64 sb_uniform64(u64 v) {
@@ -216,6 +249,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int npad = job.nty + 2;                      // blocks of a strip incl. the virtual ones above and below
     const int npos = job.ntx * npad;
+    const unsigned npad_magic = 0xffffffffu / (unsigned)npad + 1u;       // floor(p / npad) = umulhi(p, magic) for p < 2^16
 
 #ifdef SB_STAMPS
     long long acc[SB_NSTAMP], t_last = clock64();
@@ -261,6 +295,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 mine |= (i < npos && f[j] != 0) ? 1ull << (base + j) : 0ull;
             }
         }
+        SB_T(13);                                        // flag loads returned
         for (int c = 0; c < nch; ++c) {
             const u64 b = __builtin_amdgcn_ballot_w64((mine >> c) & 1ull);
             if (lane == 0) s_bits[c * NWV + wv] = b;
@@ -270,38 +305,38 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
     if (tid == 0) s_misc[4] = 0;
     if (fold_stats) wave_total_shifted_store(pm, s_wpart);
+    SB_T(14);                                            // plane, zero columns, the waves' partial sums
     __syncthreads();
-    if (fold_stats) {
-        // k_scan's shifted sums added up in k_prep's order; every thread derives the scalars itself (identical bits)
-        const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
-        T st4[4];
-        sigmoid_scalars<T>(m, st4);
-        sd = st4[0]; rr = st4[1];
-        if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
-    } else if (FLY && job.ngath > 0) { sd = s_sdr[0]; rr = s_sdr[1]; }
     const int nwords = nch * NWV;
     SB_T(11);                                            // flags -> plane, statistics
-    // ---- prologue 2: this workgroup's share.  The unit of cost is a STAGED block (an active block or a neighbour of
-    // one): workgroup b takes the active blocks that lie between the staged blocks of ranks b S / G and (b+1) S / G
-    // in strip-major order, so every workgroup marches about S / G blocks (plus at most two where a run is cut) --
-    // an equal share of ACTIVE blocks left the workgroup with the most short runs with 15 blocks against a mean of 10.
-    // Per word of the plane: active and staged blocks before it, packed (low / high 16 bits), by one workgroup scan;
-    // the array lies where the cell lists of the march will (they are not in use yet).
+    // ---- prologue 2, WAVE 0 ALONE (the others wait at one barrier): this workgroup's share and the schedule of its first
+    // round.  The unit of cost is a STAGED block (an active block or a neighbour of one): workgroup b takes the active
+    // blocks that lie between the staged blocks of ranks b S / G and (b+1) S / G in strip-major order, so every
+    // workgroup marches about S / G blocks (plus at most two where a run is cut) -- an equal share of ACTIVE blocks
+    // left the workgroup with the most short runs with 15 blocks against a mean of 10.
+    // Per word of the plane: active and staged blocks before it, packed (low / high 16 bits); the array lies where the
+    // cell lists of the march will (they are not in use while a round is planned).
     unsigned *s_pre = (unsigned *)&s_cell[0][0];
     static_assert(sizeof(s_cell) >= sizeof(unsigned) * STRIP_MAXW, "the prefix array fits where the cell lists lie");
+    auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };      // this wave's LDS writes have landed
     auto stage_word = [&](int k) -> u64 {                // staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
         const u64 a = s_bits[k], pv = k > 0 ? s_bits[k - 1] : 0ull, nx = k + 1 < nwords ? s_bits[k + 1] : 0ull;
         return a | (a << 1) | (pv >> 63) | (a >> 1) | (nx << 63);
     };
-    int tot_packed;
-    {
-        unsigned v = 0;
-        if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
-        const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tot_packed);
-        if (tid < nwords) s_pre[tid] = (unsigned)ex;
-        __syncthreads();
-    }
-    const int nact = tot_packed & 0xffff, nstaged = (int)((unsigned)tot_packed >> 16);
+    int tot_packed = 0;
+    auto make_prefix = [&]() {                           // one wave
+        int run = 0;
+        for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
+            const int k = k0 + lane;
+            const int v = k < nwords ? (int)((unsigned)__popcll(s_bits[k]) | (unsigned)__popcll(stage_word(k)) << 16) : 0;
+            const int incl = sb_wave_scan_add(v);
+            if (k < nwords) s_pre[k] = (unsigned)(run + incl - v);
+            run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
+        }
+        tot_packed = run;
+        if (lane == 0) s_misc[7] = run;
+        wave_sync();
+    };
     // the word that holds rank t of the packed prefix (hi: staged, else active) and the rank inside it; wave-uniform
     auto find_word = [&](int t, bool hi, int &n) -> int {
         int kk = -1;
@@ -326,6 +361,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     };
     // active blocks before the staged block of rank t (all of them if there is no such block)
     auto act_before_staged = [&](int t) -> int {
+        const int nact = tot_packed & 0xffff, nstaged = (int)((unsigned)tot_packed >> 16);
         if (t >= nstaged) return nact;
         int n;
         const int k = find_word(t, true, n);
@@ -334,18 +370,64 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         const u64 a = sb_uniform64(s_bits[k]);
         return (int)(__builtin_amdgcn_readfirstlane((int)s_pre[k]) & 0xffff) + __popcll(a & ((1ull << bpos) - 1ull));
     };
-    const int r_begin = act_before_staged((int)(((long long)blockIdx.x * nstaged) / G));
-    const int r_end = act_before_staged((int)(((long long)(blockIdx.x + 1) * nstaged) / G));
-    // (the position of the active block of rank r: find_word(r, false, n), then nth_bit -- used by the rounds below,
-    // which re-make s_pre if a second round has to run over the cell lists' memory)
-    SB_T(12);                                            // prefix, share
+    // The schedule of the round that holds the active blocks of ranks [ra, rb): the staged positions in ascending
+    // order with their flags, a drain step behind every run, three warm-up steps in front (they stage nothing and only
+    // issue the loads of the first three blocks, so that every load of the march is issued at the same three program
+    // points -- see `step`), padded to a multiple of three.  One lane per position, 64 positions at a time.
+    auto make_schedule = [&](int ra, int rb) {           // one wave; leaves the number of steps in s_misc[0]
+        int n0, n1;
+        const int k0w = find_word(ra, false, n0), k1w = find_word(rb - 1, false, n1);
+        const int p0 = k0w < 0 ? -1 : k0w * 64 + nth_bit(sb_uniform64(s_bits[k0w < 0 ? 0 : k0w]), n0);
+        const int p1 = k1w < 0 ? -1 : k1w * 64 + nth_bit(sb_uniform64(s_bits[k1w < 0 ? 0 : k1w]), n1);
+        wave_sync();                                     // (the prefix array may be overwritten from here on)
+        if (p0 < 1 || p1 < p0) { if (lane == 0) s_misc[0] = 0; return; }     // (cannot happen: position 0 is virtual)
+        if (lane < STRIP_DEPTH) s_ent[lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
+        if (lane < 3) s_misc[1 + lane] = 0;
+        int n_out = STRIP_DEPTH;
+        for (int c = p0 - 1; c <= p1 + 1; c += SB_WAVE) {
+            const int pp = c + lane;
+            // active blocks (of this round) at positions pp - 2 .. pp + 2: bits 0 .. 4
+            unsigned win = 0;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                const int q = pp + d - 2;
+                const bool in = q >= p0 && q <= p1;
+                const u64 w = s_bits[in ? q >> 6 : 0];
+                win |= (in && ((w >> (q & 63)) & 1ull)) ? 1u << d : 0u;
+            }
+            const bool st = pp <= p1 + 1 && (win & 0xeu) != 0u;                   // pp - 1, pp, pp + 1
+            const bool st_prev = (win & 0x7u) != 0u, st_next = (win & 0x1cu) != 0u;
+            const bool en = st && !st_next;
+            const u64 ms = __builtin_amdgcn_ballot_w64(st), me = __builtin_amdgcn_ballot_w64(en);
+            const u64 below = (1ull << lane) - 1ull;
+            const int at = n_out + __popcll(ms & below) + __popcll(me & below);
+            n_out += __popcll(ms) + __popcll(me);
+            if (st) {
+                const int sp = (int)__umulhi((unsigned)pp, npad_magic);
+                const unsigned sjv = ((unsigned)sp << 16) | (unsigned)(pp - sp * npad);
+                const unsigned e = (unsigned)pp | ((win & 1u) ? SCH_Q2 : 0u) | (st_prev ? 0u : SCH_RESTART);
+                if (at < STRIP_SCHED) s_ent[at] = make_uint2(e, sjv);
+                if (en && at + 1 < STRIP_SCHED) s_ent[at + 1] = make_uint2((unsigned)pp | SCH_DRAIN | ((win & 2u) ? SCH_Q1 : 0u), sjv);
+            }
+        }
+        // (padded to a multiple of three with steps that do nothing: the march has no early exit -- with one, the
+        // compiler's count of the loads in flight collapses and it drains the queue every third step)
+        n_out = min(n_out, STRIP_SCHED - 2);
+        const int n_pad = (n_out + STRIP_DEPTH - 1) / STRIP_DEPTH * STRIP_DEPTH;
+        if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
+        if (lane == 0) s_misc[0] = n_pad;
+    };
+    if (wv == 0) {
+        make_prefix();
+        const int rb0 = act_before_staged((int)(((long long)blockIdx.x * (int)((unsigned)tot_packed >> 16)) / G));
+        const int re0 = act_before_staged((int)(((long long)(blockIdx.x + 1) * (int)((unsigned)tot_packed >> 16)) / G));
+        if (lane == 0) { s_misc[5] = rb0; s_misc[6] = re0; }
+        if (rb0 < re0) make_schedule(rb0, min(rb0 + STRIP_ROUND, re0));
+    }
+    SB_T(12);                                            // wave 0: prefix, share, schedule; the others: nothing
+    __syncthreads();
+    const int r_begin = __builtin_amdgcn_readfirstlane(s_misc[5]), r_end = __builtin_amdgcn_readfirstlane(s_misc[6]);
 
-    const size_t fbytes = (size_t)g.nxh * g.nyh * sizeof(T);
-    ThcBufs<FLY> B;
-    B.th = sb_make_rsrc((const void *)job.theta, fbytes);                  // (theta is the t0 plane unless FLY)
-    B.zz = sb_make_rsrc(FLY ? (const void *)job.z : (const void *)job.theta, fbytes);
-    B.sg = sb_make_rsrc(FLY ? (const void *)job.sigma : (const void *)job.theta, fbytes);
-    B.cls = sb_make_rsrc(job.clsbits, (size_t)g.nyh * g.nw * 8);
     const bool fastx = g.nx > W + 2;                   // one conditional add wraps every column of a staged row
     const bool limited = g.bnd == BND_HALO;
 
@@ -385,14 +467,22 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         bool rowok = true;
         if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-        const unsigned rowb = (unsigned)Yr * (unsigned)g.nxh * (unsigned)sizeof(T), wordb = (unsigned)Yr * (unsigned)g.nw * 8u;
-        R.th = sb_buf_ld<T>(B.th, cc_colb, rowb);
-        if constexpr (FLY) { R.zz = sb_buf_ld<T>(B.zz, cc_colb, rowb); R.sg = sb_buf_ld<T>(B.sg, cc_colb, rowb); }
-        R.lw = __builtin_amdgcn_raw_buffer_load_b32(B.cls, cc_clsb, wordb, 0);
+#if defined(STRIP_EXP) && (STRIP_EXP & 1)
+        Yr = (int)((blockIdx.x * 16 + wv) % (unsigned)g.nyh);   // experiment: a workgroup re-reads its own 16 rows (cache hits)
+#endif
+        // (a scalar base -- field pointer plus the row's offset -- and the lane's 32-bit column offset: two scalar
+        // registers per field where a buffer descriptor takes four)
+        const size_t rowb = (size_t)((unsigned)Yr * (unsigned)g.nxh) * sizeof(T), wordb = (size_t)((unsigned)Yr * (unsigned)g.nw) * 8u;
+        R.th = *(const T *)((const char *)job.theta + rowb + cc_colb);                 // (theta is the t0 plane unless FLY)
+        if constexpr (FLY) {
+            R.zz = *(const T *)((const char *)job.z + rowb + cc_colb);
+            R.sg = *(const T *)((const char *)job.sigma + rowb + cc_colb);
+        }
+        R.lw = *(const uint32_t *)((const char *)job.clsbits + wordb + cc_clsb);
         R.sh = rowok ? cc_sh : -1;
     };
 
-    // running column totals of the table this wave sums along latitude (waves 8, 9: 64 bit; wave 10: the count)
+    // running column totals of the table this wave sums along latitude (waves 5, 6: 64 bit; wave 7: the count)
     u64 carry = 0;
 
     // S1: the row's registers -> ring row (prefix along longitude only)
@@ -401,15 +491,25 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         asm volatile("" : "+s"(kt));                      // (opaque: the constants are loaded here, every time)
         const bool ok = R.sh >= 0;
         const bool land = ok && ((R.lw >> (R.sh & 31)) & 1u);
+#ifdef SB_STAMPS_FINE
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (diagnostic build: the wait for the block's loads made explicit)
+#endif
+        SB_TF(18);                                        // stage: waiting for the block's loads
         T t0v = R.th;
         if constexpr (FLY) {
             // the sigmoid only where a lane of the wave stands on land (z == 0 -> t0 = theta exactly)   ref :166-167
+#if !(defined(STRIP_EXP) && (STRIP_EXP & 2))
             if (__builtin_amdgcn_ballot_w64(ok && R.zz != T(0)) != 0) t0v = strip_t0(R.th, R.zz, R.sg, sd, rr, kt);
+#endif
         }
+        SB_TF(19);                                        // stage: t0
         u64 qa = ok ? sb_to_fixed((double)t0v, kt) : 0ull;
         u64 ql = land ? qa : 0ull;
         const u64 lm = __builtin_amdgcn_ballot_w64(land);
-        sb_scan2_u64(qa, ql);
+        // (a row on one side of the coast needs one scan: its land-side sums are zero, or the sums over all cells)
+        if (lm == 0ull) sb_scan1_u64(qa);                          // wave-uniform; ql is zero everywhere
+        else if (lm == __builtin_amdgcn_ballot_w64(ok)) { sb_scan1_u64(qa); ql = qa; }
+        else sb_scan2_u64(qa, ql);
         const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u)) + (land ? 1u : 0u);
         const unsigned slot = (unsigned)(jp * C + wv) & RM;
         const unsigned o = __umul24(slot, P) + lane + 1;
@@ -427,12 +527,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         }
     };
 
-    // S2, waves 8-10: prefix along latitude of the 16 rows of the block at ring position jp
+    // S2, waves 5-7: prefix along latitude of the 16 rows of the block at ring position jp
     auto vertical = [&](int jp) __attribute__((always_inline)) {
         const unsigned r0 = (unsigned)(jp * C) & RM;     // a block never straddles the end of the ring (128 = 8 x 16)
         const unsigned o = __umul24(r0, P) + lane + 1;
-        if (wv < 10) {
-            u64 *tab = (wv == 8 ? sA : sL) + o;
+        if (wv < 7) {
+            u64 *tab = (wv == 5 ? sA : sL) + o;
 #pragma unroll
             for (int h0 = 0; h0 < C; h0 += 8) {          // eight rows of reads in flight
                 u64 v[8];
@@ -459,7 +559,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // issued before it.
     struct BandWords { u64 a0, b0, a1, b1, c0, c1; int sh; };   // c: land-side word of the last longitude (f2py rule)
     auto band_issue = [&](int strip, int jp) __attribute__((always_inline)) -> BandWords {
-        const int k = min(wv, C / 2 - 1);
+        const int k = max(wv - C / 2, 0);                // the listing waves are 8 .. 15: two rows each
         const int y0 = (jp - 1) * C + 2 * k;
         const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
         const int xa = strip * SW + g.h;                 // array column of the strip's first owned cell
@@ -478,31 +578,33 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         return w;
     };
 
-    // S1, waves 0-7: the band cells of two rows of the queried block -> the step's compact list.  A cell's code is
+    // S1, waves 8-15: the band cells of two rows of the queried block -> the step's compact list.  A cell's code is
     // row << 5 | column, plus (f2py rule, last longitude only) bit 10 and in bit 9 its own land-side bit -- see `query`.
     // The waves reserve their entries with one LDS atomic each: the order of the list is of no consequence.
+    const unsigned cell_code = (unsigned)((2 * max(wv - C / 2, 0) + (lane >> 5)) << 5 | (lane & (SW - 1)));   // row << 5 | column
     auto list_cells = [&](int strip, int jp, const BandWords &bwd, int buf) __attribute__((always_inline)) {
-        const int lx = lane & (SW - 1), ly = 2 * min(wv, C / 2 - 1) + (lane >> 5);
-        const int x = strip * SW + lx, y = (jp - 1) * C + ly;
-        // (the four words are scalars: shift each by the lane's amount, then select -- a select between the words
-        // themselves makes the compiler index them in scratch memory)
-        const int bp = bwd.sh + lx;
-        const unsigned sa = (unsigned)(bp & 63);
-        const unsigned bit0 = (unsigned)((bp < 64 ? bwd.a0 >> sa : bwd.b0 >> sa) & 1ull);
-        const unsigned bit1 = (unsigned)((bp < 64 ? bwd.a1 >> sa : bwd.b1 >> sa) & 1ull);
-        const bool isband = x < g.nx && y >= 0 && y < g.rows && ((lane >> 5) ? bit1 : bit0) != 0u;
-        const u64 m = __builtin_amdgcn_ballot_w64(isband);
+        // the wave's 64 band bits (lanes 0-31: first row, 32-63: second) by scalar funnel shifts of the four words
+        const int y0 = (jp - 1) * C + 2 * max(wv - C / 2, 0);
+        const int ncol = min(g.nx - strip * SW, SW);      // owned columns that exist (the last strip may be cut)
+        const unsigned colmask = ncol >= 32 ? 0xffffffffu : (1u << ncol) - 1u;
+        auto row_bits = [&](u64 a, u64 b2, int y) -> unsigned {
+            const u64 f = bwd.sh ? (a >> bwd.sh) | (b2 << (64 - bwd.sh)) : a;
+            return (y >= 0 && y < g.rows) ? (unsigned)f & colmask : 0u;
+        };
+        const u64 m = (u64)row_bits(bwd.a0, bwd.b0, y0) | (u64)row_bits(bwd.a1, bwd.b1, y0 + 1) << 32;
         if (m == 0) return;                              // wave-uniform
-        unsigned code = (unsigned)(ly << 5 | lx);
-        if (g.bnd == BND_WRAPPER && x == g.nx - 1) {
-            const unsigned sl = (unsigned)((g.nx - 1 + g.h) & 63);
-            code |= 1u << 10 | (unsigned)(((lane >> 5) ? (bwd.c1 >> sl) : (bwd.c0 >> sl)) & 1ull) << 9;
+        unsigned code = cell_code;
+        if (g.bnd == BND_WRAPPER && strip == job.ntx - 1) {      // uniform: the strip that owns the last longitude
+            if (strip * SW + (int)(lane & (SW - 1)) == g.nx - 1) {
+                const unsigned sl = (unsigned)((g.nx - 1 + g.h) & 63);
+                code |= 1u << 10 | (unsigned)(((lane >> 5) ? (bwd.c1 >> sl) : (bwd.c0 >> sl)) & 1ull) << 9;
+            }
         }
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_misc[1 + buf], __popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
         const unsigned at = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (isband) s_cell[buf][at] = (unsigned short)code;
+        if ((m >> lane) & 1ull) s_cell[buf][at] = (unsigned short)code;
     };
 
     // S2, waves 0 ..: 64 entries of the list per wave: bisection for the radius, contrast, result
@@ -526,19 +628,30 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             const unsigned r1 = __umul24((rho + rad) & RM, P) + cx, r0 = __umul24((rho - rad - 1) & RM, P) + cx;
             return (int)(unsigned short)((unsigned)sC[r1 + rad] - (unsigned)sC[r0 + rad] - (unsigned)sC[r1 - rad - 1] + (unsigned)sC[r0 - rad - 1]);
         };
-        // the widest square, then a branch-free bisection (1 + log2 H probes of 4 reads)
-        int nl = count(limc);
-        const bool got = nl > 0 && nl < (2 * limc + 1) * (2 * limc + 1);
-        const bool found = valid && lim >= 1 && got;
-        int lo = got ? 1 : limc, hi = limc;
+        // Two rounds of independent probes -- radii 4, 8, 12, 16, then the three radii below the smallest of those that
+        // holds both classes: 28 reads in two LDS round trips, where a bisection makes 20 reads in five.  The march is
+        // bound by the length of its dependent chains, not by LDS issue.
+        int nl1[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const int nlm = count(mid);
-            const bool act = lo < hi, okm = nlm > 0 && nlm < (2 * mid + 1) * (2 * mid + 1);
-            nl = (act && okm) ? nlm : nl;
-            hi = (act && okm) ? mid : hi;
-            lo = (act && !okm) ? mid + 1 : lo;
+        for (int k = 0; k < 4; ++k) nl1[k] = count(limited ? min(4 * (k + 1), limc) : 4 * (k + 1));
+        int lo = 1, hi = limc, nl = 0;
+        bool got = false;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const int rad = limited ? min(4 * (k + 1), limc) : 4 * (k + 1);
+            const bool mixed = nl1[k] > 0 && nl1[k] < (2 * rad + 1) * (2 * rad + 1);
+            if (mixed) { hi = rad; nl = nl1[k]; got = true; }
+            else if (rad < hi) lo = max(lo, rad + 1);
+        }
+        const bool found = valid && lim >= 1 && got;
+        if (!got) lo = max(1, hi - 3);                   // (probes in bounds; their results are not used)
+        int nl2[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) nl2[m] = count(min(lo + m, hi));
+#pragma unroll
+        for (int m = 2; m >= 0; --m) {
+            const int rad = lo + m;
+            if (rad < hi && nl2[m] > 0 && nl2[m] < (2 * rad + 1) * (2 * rad + 1)) { hi = rad; nl = nl2[m]; }
         }
         const int nn = hi, area = (2 * nn + 1) * (2 * nn + 1);
         const unsigned r1 = __umul24((rho + nn) & RM, P) + cx, r0 = __umul24((rho - nn - 1) & RM, P) + cx;
@@ -577,74 +690,26 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     SB_T(0);                                             // prologue
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
     for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
-        const int rb = min(ra + STRIP_ROUND, r_end);
-        if (ra > r_begin) {                              // (a further round: the prefix array was overwritten by cell lists)
-            unsigned v = 0;
-            if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
-            int tp;
-            const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tp);
-            if (tid < nwords) s_pre[tid] = (unsigned)ex;
+        if (ra > r_begin) {                              // (a further round: wave 0 plans it; the cell lists lay over the prefix array)
+            if (wv == 0) { make_prefix(); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
             __syncthreads();
         }
-        int n0, n1;
-        const int k0w = find_word(ra, false, n0), k1w = find_word(rb - 1, false, n1);
-        const int p0 = k0w < 0 ? -1 : k0w * 64 + nth_bit(sb_uniform64(s_bits[k0w < 0 ? 0 : k0w]), n0);
-        const int p1 = k1w < 0 ? -1 : k1w * 64 + nth_bit(sb_uniform64(s_bits[k1w < 0 ? 0 : k1w]), n1);
-        if (p0 < 1 || p1 < p0) break;                    // (cannot happen: ranks below the count exist, position 0 is virtual)
-        // -- the schedule: staged positions in ascending order with their flags, by wave 0 --
-        // act = active blocks of this round; staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
-        const int kw0 = p0 >> 6, kw1 = p1 >> 6;
-        if (wv == 0) {
-            // (three warm-up steps lead the schedule: they stage nothing and only issue the loads of the first three
-            // blocks, so that every load of the loop is issued at the same three program points -- see `step`)
-            if (lane < STRIP_DEPTH) s_ent[lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
-            if (lane < 3) s_misc[1 + lane] = 0;
-            int n_out = STRIP_DEPTH;
-            for (int kb = kw0 - 1; kb <= kw1 + 1; kb += SB_WAVE) {
-                const int k = kb + lane;
-                u64 a[5];
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    const int kk = k + d - 2;
-                    u64 w = (kk >= kw0 && kk <= kw1) ? s_bits[kk] : 0ull;
-                    if (kk == kw0) w &= ~0ull << (p0 & 63);
-                    if (kk == kw1) w &= ~0ull >> (63 - (p1 & 63));
-                    a[d] = w;
-                }
-                auto st_of = [&](u64 prev, u64 cur, u64 next) { return cur | (cur << 1) | (prev >> 63) | (cur >> 1) | (next << 63); };
-                const u64 s_prev = st_of(a[0], a[1], a[2]), s_cur = st_of(a[1], a[2], a[3]), s_next = st_of(a[2], a[3], a[4]);
-                u64 st = (k >= kw0 - 1 && k <= kw1 + 1 && k >= 0 && k < STRIP_MAXW) ? s_cur : 0ull;
-                const u64 q2 = (a[2] << 2) | (a[1] >> 62), q1 = (a[2] << 1) | (a[1] >> 63);
-                const u64 rs = st & ~((s_cur << 1) | (s_prev >> 63)), en = st & ~((s_cur >> 1) | (s_next << 63));
-                const int pc = __popcll(st) + __popcll(en);     // a drain step follows the last block of a run
-                const int incl = sb_wave_scan_add(pc);
-                int at = n_out + incl - pc;
-                n_out += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
-                while (st) {
-                    const int b = __ffsll((unsigned long long)st) - 1;
-                    st &= st - 1;
-                    const int pp = k * 64 + b, sp = pp / npad;
-                    const unsigned sjv = ((unsigned)sp << 16) | (unsigned)(pp - sp * npad);
-                    unsigned e = (unsigned)pp;
-                    e |= ((q2 >> b) & 1ull) ? SCH_Q2 : 0u;
-                    e |= ((rs >> b) & 1ull) ? SCH_RESTART : 0u;
-                    if (at < STRIP_SCHED) s_ent[at] = make_uint2(e, sjv);
-                    ++at;
-                    if ((en >> b) & 1ull) {
-                        if (at < STRIP_SCHED) s_ent[at] = make_uint2((unsigned)pp | SCH_DRAIN | (((q1 >> b) & 1ull) ? SCH_Q1 : 0u), sjv);
-                        ++at;
-                    }
+        if (fold_stats && ra == r_begin) {
+            // k_scan's shifted sums added up in k_prep's order and turned into the sigmoid scalars -- two divisions and a
+            // square root in fp64, some 200 dependent instructions -- by the last wave alone, while the others issue the
+            // loads of the first blocks; everybody picks the scalars up behind the barrier that opens the first run
+            if (wv == NWV - 1) {
+                const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
+                T st4[4];
+                sigmoid_scalars<T>(m, st4);
+                if (lane == 0) {
+                    s_sdr[0] = st4[0]; s_sdr[1] = st4[1];
+                    if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
                 }
             }
-            // (padded to a multiple of three with steps that do nothing: the loop below has no early exit -- with one,
-            // the compiler's count of the loads in flight collapses and it drains the queue every third step)
-            n_out = min(n_out, STRIP_SCHED - 2);
-            const int n_pad = (n_out + STRIP_DEPTH - 1) / STRIP_DEPTH * STRIP_DEPTH;
-            if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
-            if (lane == 0) s_misc[0] = n_pad;
         }
-        __syncthreads();
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        if (nst == 0) break;
         // a step's entry travels in scalar registers from the step that issues its block's loads (three steps ahead)
         // to the step itself; behind the end of the schedule: idle steps
         auto entry = [&](int i, unsigned &e, unsigned &j) __attribute__((always_inline)) {
@@ -672,22 +737,33 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             const bool drain = (ent & SCH_DRAIN) != 0, idle = (ent & SCH_IDLE) != 0;
             const int qoff = drain ? 1 : 2;
             const bool qany = (ent & (drain ? SCH_Q1 : SCH_Q2)) != 0;
+            SB_TF(16);                                    // entry decode
             if (!idle) {
-                if (ent & SCH_RESTART) lds_barrier();             // the queries of the run before have left the ring
+                if (ent & SCH_RESTART) {
+                    lds_barrier();                                // the queries of the run before have left the ring
+                    if (FLY && (fold_stats || job.ngath > 0)) { sd = s_sdr[0]; rr = s_sdr[1]; }
+                }
                 BandWords bwd;
-                const bool lister = qany && wv < C / 2;
+                const bool lister = qany && wv >= C / 2;
                 if (lister) bwd = band_issue(strip, jp - qoff);
+                SB_TF(17);                                // restart barrier, band words issued
                 if (tid == STRIP_NT - 1) s_misc[1 + (buf == 2 ? 0 : buf + 1)] = 0;   // the next step's list starts empty
                 if (!drain) stage(R, ent, jp);
+                SB_TF(20);                                // stage: the rest (scans, LDS writes)
+#if !(defined(STRIP_EXP) && (STRIP_EXP & 8))
                 if (lister) list_cells(strip, jp - qoff, bwd, buf);
+#endif
             }
+            SB_TF(21);                                    // list of band cells
             issue(R, J);                                          // (the one place of this copy of the step that loads)
             SB_T(2);                                     // S1 (incl. the wait for the block's loads)
             if (!idle) {
                 lds_barrier();
                 SB_T(3);                                 // barrier
-                if (wv >= 8) { if (!drain && wv < 11) vertical(jp); }
-                else if (qany) query(pos - qoff, strip, jp - qoff, buf);
+#if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
+                if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf);
+#endif
+                if (!drain && wv >= 5 && wv < 8) vertical(jp);
                 SB_T(4);                                 // S2
 #ifdef SB_STAMPS
                 acc[drain ? 5 : 6] += 1;
@@ -707,14 +783,9 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // global-memory search; everything it needs comes from the job's copy in device memory ----
     if (s_misc[4] != 0) {                                // (uniform: read behind the round's last barrier)
         const DiagJob<T> &cj = *job.cold;
-        {                                                // the prefix array again (the cell lists lay over it)
-            unsigned v = 0;
-            if (tid < nwords) v = (unsigned)__popcll(s_bits[tid]) | (unsigned)__popcll(stage_word(tid)) << 16;
-            int tp;
-            const int ex = thc_block_excl_scan<STRIP_NT>((int)v, s_scan, tp);
-            if (tid < nwords) s_pre[tid] = (unsigned)ex;
-            __syncthreads();
-        }
+        if (wv == 0) make_prefix();                      // the prefix array again (the cell lists lay over it)
+        __syncthreads();
+        tot_packed = s_misc[7];
         for (int r = r_begin; r < r_end; ++r) {
             int n;
             const int kw = find_word(r, false, n);
