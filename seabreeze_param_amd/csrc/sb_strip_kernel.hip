@@ -687,6 +687,22 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         if (lane == SB_WAVE - 1 && nnmax > 1) atomicMax(&job.flags[qpos], nnmax);
     };
 
+    // k_scan's shifted sums added up in k_prep's order and turned into the sigmoid scalars -- two divisions and a square
+    // root in fp64, some 200 dependent instructions -- by the last wave alone, while the others issue the loads of the
+    // first blocks; everybody picks the scalars up behind the barrier that opens the first run.  Workgroup 0 publishes
+    // them (for the calls that reuse them: static sigma), with or without a share of the march.
+    auto finish_stats = [&]() {
+        if (wv == NWV - 1) {
+            const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
+            T st4[4];
+            sigmoid_scalars<T>(m, st4);
+            if (lane == 0) {
+                s_sdr[0] = st4[0]; s_sdr[1] = st4[1];
+                if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
+            }
+        }
+    };
+    if (fold_stats && r_begin >= r_end && blockIdx.x == 0) finish_stats();
     SB_T(0);                                             // prologue
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
     for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
@@ -694,20 +710,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             if (wv == 0) { make_prefix(); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
             __syncthreads();
         }
-        if (fold_stats && ra == r_begin) {
-            // k_scan's shifted sums added up in k_prep's order and turned into the sigmoid scalars -- two divisions and a
-            // square root in fp64, some 200 dependent instructions -- by the last wave alone, while the others issue the
-            // loads of the first blocks; everybody picks the scalars up behind the barrier that opens the first run
-            if (wv == NWV - 1) {
-                const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
-                T st4[4];
-                sigmoid_scalars<T>(m, st4);
-                if (lane == 0) {
-                    s_sdr[0] = st4[0]; s_sdr[1] = st4[1];
-                    if (blockIdx.x == 0) { for (int i = 0; i < 4; ++i) job.stats_out[i] = st4[i]; }
-                }
-            }
-        }
+        if (fold_stats && ra == r_begin) finish_stats();
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
         if (nst == 0) break;
         // a step's entry travels in scalar registers from the step that issues its block's loads (three steps ahead)
