@@ -104,19 +104,22 @@ __device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
     return q;
 }
 // t0 = theta - (gmma*z)*sigmoid(sigma)   ref: generic/sea_breeze_diag.f90:166-167,478-480 (as sb_t0)
+// (no branch for sea level: there gmma * z is a signed zero, the product with the -- finite or NaN -- sigmoid too, and
+// theta comes back bit for bit, or NaN exactly where the reference's expression gives NaN)
 __device__ __forceinline__ double strip_t0(double theta, double z, double sigma, double sd, double r, sb_cdp k) {
-    if (z == 0.0) return theta;
     return theta - ((SB_K(18, -0.0060956) * z) * strip_logistic_of_neg(-sd * (sigma - r), k));
 }
 __device__ __forceinline__ float strip_t0(float theta, float z, float sigma, float sd, float r, sb_cdp) {
     return sb_t0<float>(theta, z, sigma, sd, r);
 }
 
-// t0 (K) -> fixed point.  fma rounds x * 2^40 + 1.5 * 2^52 to an integer held in the mantissa (|x| <= 1024).
+// t0 (K) -> fixed point, BIASED: fma rounds x * 2^40 + 1.5 * 2^52 to an integer held in the mantissa (|x| < 2048 K:
+// anything a temperature can be; beyond, the sums are garbage, not a fault), and the bits of that double are the value
+// plus the constant SB_FIX_BIAS.  The bias stays in the tables -- a window of n cells holds n of them, which the
+// query takes out again -- so a staged cell costs one instruction here instead of five (clamps, 64-bit subtraction).
+#define SB_FIX_BIAS 0x4338000000000000ull
 __device__ __forceinline__ u64 sb_to_fixed(double x, sb_cdp k) {
-    x = fmin(fmax(x, -1024.0), 1024.0);
-    const double y = __builtin_fma(x, SB_K(16, 0x1p40), SB_K(17, 0x1.8p52));
-    return (u64)(__double_as_longlong(y) - 0x4338000000000000ll);
+    return (u64)__double_as_longlong(__builtin_fma(x, SB_K(16, 0x1p40), SB_K(17, 0x1.8p52)));
 }
 
 // inclusive prefix sums over the 64 lanes of a wave of two 64-bit integers at once: per step and value one
@@ -201,7 +204,7 @@ struct StripRegs {
     T th;                          // theta (FLY) or t0
     T zz, sg;                      // z, sigma (FLY only)
     uint32_t lw;                   // the 32-bit half of the land-side word that holds the cell
-    int sh;                        // the cell's bit in lw; -1: no such cell
+    uint32_t lbit;                 // the cell's bit in lw; 0: no such cell
 };
 
 // schedule entry of a step: position | flags
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
 
     // the lane's column of the strip the loads are issued for: byte offsets in a field row and in a row of the
     // land-side plane, bit in the 32-bit word (-1: no such cell); recomputed when the strip changes
-    int cc_strip = -1, cc_sh = -1;
-    unsigned cc_colb = 0, cc_clsb = 0;
+    int cc_strip = -1;
+    unsigned cc_colb = 0, cc_clsb = 0, cc_lbit = 0;
 
     // loads of row wv of block jp of `strip`
     // (always four loads, also behind the end of the schedule and for a drain step, from clamped addresses: the
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             const unsigned xc = ok ? (unsigned)Xc : 0u;  // every load is unconditional, from a clamped address
             cc_colb = xc * (unsigned)sizeof(T);
             cc_clsb = (xc >> 5) * 4u;
-            cc_sh = ok ? (int)(xc & 31u) : -1;
+            cc_lbit = ok ? 1u << (xc & 31u) : 0u;
         }
         const int ys = (jp - 1) * C + wv;               // interior row (may lie outside the grid: clamped or absent)
         int Yr;
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             R.sg = *(const T *)((const char *)job.sigma + rowb + cc_colb);
         }
         R.lw = *(const uint32_t *)((const char *)job.clsbits + wordb + cc_clsb);
-        R.sh = rowok ? cc_sh : -1;
+        R.lbit = rowok ? cc_lbit : 0u;
     };
 
     // running column totals of the table this wave sums along latitude (waves 5, 6: 64 bit; wave 7: the count)
@@ -488,29 +491,26 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // S1: the row's registers -> ring row (prefix along longitude only)
     auto stage = [&](StripRegs<T, FLY> &R, unsigned ent, int jp) __attribute__((always_inline)) {
         sb_cdp kt = (sb_cdp)sb_strip_k;
-        asm volatile("" : "+s"(kt));                      // (opaque: the constants are loaded here, every time)
-        const bool ok = R.sh >= 0;
-        const bool land = ok && ((R.lw >> (R.sh & 31)) & 1u);
-#ifdef SB_STAMPS_FINE
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (diagnostic build: the wait for the block's loads made explicit)
-#endif
-        SB_TF(18);                                        // stage: waiting for the block's loads
+        asm volatile("" : "+s"(kt));                      // (opaque: with STRIP_KTAB the constants are loaded here, every time)
+        // Predicates as one compare each, straight into a lane mask (an `a && b` of two of them costs two more vector
+        // instructions to re-form the mask): the land-side bit is tested against a per-lane bit that is zero where the
+        // cell does not exist.
+        const u64 lm = __builtin_amdgcn_ballot_w64((R.lw & R.lbit) != 0u);
         T t0v = R.th;
         if constexpr (FLY) {
-            // the sigmoid only where a lane of the wave stands on land (z == 0 -> t0 = theta exactly)   ref :166-167
-#if !(defined(STRIP_EXP) && (STRIP_EXP & 2))
-            if (__builtin_amdgcn_ballot_w64(ok && R.zz != T(0)) != 0) t0v = strip_t0(R.th, R.zz, R.sg, sd, rr, kt);
-#endif
+            // the sigmoid only where a lane of the wave stands above sea level (z == 0 -> t0 = theta exactly)   ref :166-167
+            if (__builtin_amdgcn_ballot_w64(R.zz != T(0)) != 0) t0v = strip_t0(R.th, R.zz, R.sg, sd, rr, kt);
         }
-        SB_TF(19);                                        // stage: t0
-        u64 qa = ok ? sb_to_fixed((double)t0v, kt) : 0ull;
-        u64 ql = land ? qa : 0ull;
-        const u64 lm = __builtin_amdgcn_ballot_w64(land);
+        u64 qa = sb_to_fixed((double)t0v, kt);
+        if (limited) { if (R.lbit == 0u) qa = 0ull; }    // (ghost-celled frames only: columns and rows beyond the frame)
+        u64 ql = ((R.lw & R.lbit) != 0u) ? qa : 0ull;
         // (a row on one side of the coast needs one scan: its land-side sums are zero, or the sums over all cells)
-        if (lm == 0ull) sb_scan1_u64(qa);                          // wave-uniform; ql is zero everywhere
-        else if (lm == __builtin_amdgcn_ballot_w64(ok)) { sb_scan1_u64(qa); ql = qa; }
+        if (lm == 0ull) sb_scan1_u64(qa);                // wave-uniform; ql is zero everywhere
+        else if (lm == ~0ull) { sb_scan1_u64(qa); ql = qa; }
         else sb_scan2_u64(qa, ql);
-        const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u)) + (land ? 1u : 0u);
+        // land-side cells up to and including the lane's: those of lanes 1 .. lane by mbcnt on the mask shifted down, lane 0's added
+        const u64 lm1 = lm >> 1;
+        const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm1, (unsigned)(lm & 1ull)));
         const unsigned slot = (unsigned)(jp * C + wv) & RM;
         const unsigned o = __umul24(slot, P) + lane + 1;
         sA[o] = qa;
@@ -658,8 +658,9 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         const u64 l11 = sL[r1 + nn], l01 = sL[r0 + nn], l10 = sL[r1 - nn - 1], l00 = sL[r0 - nn - 1];
         const u64 q11 = sA[r1 + nn], q01 = sA[r0 + nn], q10 = sA[r1 - nn - 1], q00 = sA[r0 - nn - 1];
         const u64 ownw = s_land[rho & RM];
-        const long long RL = (long long)((l11 - l01) - (l10 - l00));      // exact: the tables wrap, the window sum does not
-        const long long RS = (long long)((q11 - q01) - (q10 - q00)) - RL; // sea side
+        // exact: the tables wrap, the window sum does not; every cell of the window carries the fixed-point bias
+        const long long RL = (long long)((l11 - l01) - (l10 - l00) - (u64)nl * SB_FIX_BIAS);
+        const long long RS = (long long)((q11 - q01) - (q10 - q00) - (u64)area * SB_FIX_BIAS) - RL;      // sea side
         // land mean - sea mean = (RL ns - RS nl) / (nl ns): one reciprocal of an exact small integer (v_rcp_f64 + two
         // Newton steps: within an ulp of the quotient)
         auto to_f64 = [](long long v) { return __builtin_fma((double)(int)(v >> 32), 0x1p32, (double)(unsigned)v); };
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         entry(0, E0, J0); entry(1, E1, J1); entry(2, E2, J2);
         StripRegs<T, FLY> R0, R1, R2;
         R0.th = R1.th = R2.th = T(0); R0.zz = R1.zz = R2.zz = T(0); R0.sg = R1.sg = R2.sg = T(0);
-        R0.lw = R1.lw = R2.lw = 0u; R0.sh = R1.sh = R2.sh = -1;
+        R0.lw = R1.lw = R2.lw = 0u; R0.lbit = R1.lbit = R2.lbit = 0u;
         SB_T(1);                                         // pick, schedule
         // A step: S1 of block i (and the list of the band cells to query), barrier, S2 (sums along latitude || queries
         // of the block two up); a drain step (behind the last block of a run) has no block and queries the block one
