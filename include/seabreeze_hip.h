@@ -88,6 +88,12 @@ int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
    k_wind's segment lists itself (on, the default) or leave that to a kernel of its own between k_scan and
    the contrast kernel (off).  A measurement and test knob: results never depend on it.                  */
 int  sb_set_fold(sb_ctx *ctx, int on);
+/* The strip contrast kernel's plan -- which blocks each workgroup marches over, in which order, and where their
+   coastal-band cells lie -- follows from the band plane (|mask| <= maxdist) alone.  It is kept in device memory from
+   call to call; k_scan compares every word of the plane it writes with the word the call before left, and the first
+   difference makes the kernel plan afresh (on, the default).  Off: it plans every call.  A measurement and test
+   knob: results never depend on it.                                                                       */
+int  sb_set_plan_cache(sb_ctx *ctx, int on);
 /* Opt-in, off by default: the caller states that sigma (the sub-grid orography deviation, an ancillary that a
    host model reads once; ref: generic/sea_breeze_diag.f90:159-166 recomputes its mean and deviation every
    call) does not change between calls.  The first complete diag / band step after the switch forms the

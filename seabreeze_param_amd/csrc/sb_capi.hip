@@ -56,13 +56,19 @@ struct sb_ctx {
     bool stats_valid = false;
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
+    int no_plan_cache = 0;              // sb_set_plan_cache(ctx, 0): the strip kernel plans its march afresh every call
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
     int stats_ngathered = 0;            // bands whose moments the kept scalars were merged from (0: this domain's own)
     // what the last diag / band step enqueued (sb_last_step_report)
     int rep_launches = 0, rep_rccl = 0, rep_groups = 0, rep_copies = 0;
     // workspace (grow-only)
-    DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps, jobcopy;
+    DevBuf t0, bandbits, clsbits, tiles, vecs, nws, nwd, coastbits, tile_list, seg_list, stamps, jobcopy, plan;
+    // the strip kernel's plan (sb_strip_kernel.hip): [64 bytes: number of the last call whose band plane changed |
+    // ncu x SB_PLAN_STRIDE]; plan_key: the geometry it was made for; call_seq numbers the diag calls
+    int plan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const void *plan_bits = nullptr;
+    int call_seq = 0, plan_use = 0;
     int tiles_n = 0, tiles_strip = -1, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
@@ -227,6 +233,35 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     if ((rc = ensure(c, c->jobcopy, sizeof(DiagJob<double>)))) return rc;
     job.self = (DiagJob<T> *)c->jobcopy.p;
+    job.plan = nullptr; job.plan_gen = nullptr; job.call_id = 0; job.plan_use = 0;
+    if (strip) {
+        const size_t need = 64 + (size_t)c->ncu * SB_PLAN_STRIDE;
+        if (c->plan.cap < need) {
+            if ((rc = ensure(c, c->plan, need))) return rc;
+            HIPCHK(c, hipDeviceSynchronize());
+            HIPCHK(c, hipMemsetAsync(c->plan.p, 0, need, st));   // no plan stored, no change seen
+            c->plan_bits = nullptr;
+        }
+        if (phases & 1) {
+            // a new call: its number, and whether the stored plan was made for this geometry, by this many workgroups,
+            // from planes that live where this call's do
+            if (c->call_seq == 0x7fffffff) {                 // (the numbers start over: nothing stored counts)
+                HIPCHK(c, hipDeviceSynchronize());
+                HIPCHK(c, hipMemsetAsync(c->plan.p, 0, need, st));
+                c->call_seq = 0;
+                c->plan_bits = nullptr;
+            }
+            ++c->call_seq;
+            const int key[8] = {g.nx, g.ny, g.h, g.bnd, g.rows, c->ncu, tx, ty};
+            c->plan_use = c->plan_bits == c->bandbits.p && std::memcmp(key, c->plan_key, sizeof(key)) == 0 ? 1 : 0;
+            std::memcpy(c->plan_key, key, sizeof(key));
+            c->plan_bits = c->bandbits.p;
+        }
+        job.plan = (char *)c->plan.p + 64;
+        job.plan_gen = (int *)c->plan.p;
+        job.call_id = c->call_seq;
+        job.plan_use = c->no_plan_cache ? 0 : c->plan_use;
+    } else if (phases & 1) c->plan_bits = nullptr;           // (the tile kernel rewrites nothing of the plan, but k_scan does not watch the plane for it)
     job.stamps = nullptr;
 #ifdef SB_STAMPS
     if ((rc = ensure(c, c->stamps, (size_t)4096 * SB_NSTAMP * sizeof(long long)))) return rc;
@@ -944,7 +979,7 @@ int sb_destroy(sb_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&c->t0, &c->bandbits, &c->clsbits, &c->tiles, &c->vecs, &c->nws, &c->nwd, &c->coastbits, &c->tile_list,
-                      &c->seg_list, &c->stamps, &c->jobcopy})
+                      &c->seg_list, &c->stamps, &c->jobcopy, &c->plan})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : c->stage)
         if (b.p) (void)hipFree(b.p);
@@ -1405,6 +1440,12 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
 int sb_set_fold(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     c->no_fold = on ? 0 : 1;
+    return SB_OK;
+}
+
+int sb_set_plan_cache(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->no_plan_cache = on ? 0 : 1;
     return SB_OK;
 }
 

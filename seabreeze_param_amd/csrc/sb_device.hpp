@@ -228,6 +228,13 @@ struct SbSegEntry {
     uint64_t word;
     uint32_t seg, pad;
 };
+// the strip kernel's plan, per workgroup: 16 ints (call that stored it or 0, steps, first and last rank of its share),
+// the steps (8 bytes each), the cell lists of up to SB_PLAN_NQ query steps (8 x 64 codes of 16 bits, 0xffff: none)
+#define SB_PLAN_SCHED 384
+#define SB_PLAN_NQ 64
+#define SB_PLAN_ENT_OFF 64
+#define SB_PLAN_LIST_OFF (SB_PLAN_ENT_OFF + 8 * SB_PLAN_SCHED)
+#define SB_PLAN_STRIDE (SB_PLAN_LIST_OFF + 1024 * SB_PLAN_NQ)
 #define SB_SEG_PARTS 64              // k_prep workgroups that compact the segment list, one sub-list each
 
 template <typename T>
@@ -265,6 +272,13 @@ struct DiagJob {
                                     //   row-major for the tile kernel; strip-major with a virtual block above and below
                                     //   every strip for the strip kernel (sb_strip_kernel.hip)
     int strip;                      // 1: the strip kernel runs the contrast (LDS halo <= 16)
+    // the strip kernel's plan (its share of the blocks, the order of its steps, the band cells of every block it
+    // queries) depends on the band plane alone; it is kept from call to call and remade when k_scan finds that the
+    // plane changed -- see sb_strip_kernel.hip
+    char *plan;                     // per workgroup: header, steps, cell lists (SB_PLAN_STRIDE bytes)
+    int *plan_gen;                  // number of the last call whose band plane differed from that of the call before
+    int call_id;                    // number of this call (> 0, ascending)
+    int plan_use;                   // 1: a plan stored by a call no older than *plan_gen may be used
     int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius
     int *ticket;                    // spare device word (zeroed by k_scan)
     // lists k_prep compacts between k_scan and the kernels that consume them
@@ -305,6 +319,9 @@ struct StripJob {
     SbSegEntry *seg_list;
     int *seg_count;
     const DiagJob<T> *cold;         // the whole job in device memory (k_scan wrote it): slow path, band-step update
+    char *plan;                     // as DiagJob
+    const int *plan_gen;
+    int call_id, plan_use;
     long long *stamps;              // diagnostic build only
 };
 

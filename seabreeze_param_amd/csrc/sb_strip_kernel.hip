@@ -213,6 +213,7 @@ struct StripRegs {
 #define SCH_DRAIN (1u << 18)       // no block: the step behind the last block of a run, in which ...
 #define SCH_Q1 (1u << 19)          // ... the block one position up (the run's last active one) is queried
 #define SCH_IDLE (1u << 20)        // nothing but the loads of the block three steps on (warm-up and padding steps)
+#define SCH_QI_SHIFT 22            // bits 22 .. 27: number of the step's cell list in the stored plan
 
 typedef const __attribute__((address_space(4))) u64 *cu64p;          // read-only planes: scalar loads
 
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
     constexpr int RM = STRIP_RING - 1;
     static_assert(NWV == C && SW == 32, "one staged row per wave, 32 owned columns");
+    static_assert(STRIP_SCHED == SB_PLAN_SCHED, "a stored plan holds one round's steps");
     __shared__ u64 sA[STRIP_RING * P];                 // prefix sums of t0 (fixed point), every cell
     __shared__ u64 sL[STRIP_RING * P];                 // ... land-side cells
     __shared__ unsigned short sC[STRIP_RING * P];      // ... land-side count (modulo 2^16: a window holds < 2^16 cells)
@@ -241,10 +243,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     __shared__ unsigned short s_cell[3][SW * C];       // the band cells of the block a step queries, compacted (three steps in flight)
     __shared__ Moments s_wpart[NWV];
     __shared__ int s_scan[NWV];
-    __shared__ int s_misc[8];                          // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked
+    __shared__ int s_misc[12];                         // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked,
+                                                       // [5], [6] the share (ranks of active blocks), [7] totals of the plane,
+                                                       // [8] the plan of this call is stored (incl. its cell lists)
     __shared__ T s_sdr[2];
     static_assert(sizeof(u64) * (2 * STRIP_RING * P + STRIP_RING + STRIP_MAXW) + 2 * STRIP_RING * P + 8 * STRIP_SCHED +
-                          6 * SW * C + sizeof(Moments) * NWV + 4 * NWV + 32 + 16 <= 160 * 1024,
+                          6 * SW * C + sizeof(Moments) * NWV + 4 * NWV + 48 + 16 <= 160 * 1024,
                   "k_strip: LDS of one workgroup");
 
     const Geo g = job.g;
@@ -283,7 +287,19 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         }
     } else if (FLY) { sd = job.stats[0]; rr = job.stats[1]; }
     const int nch = (npos + STRIP_NT - 1) / STRIP_NT;            // <= STRIP_MAXW / 16 (host)
-    {
+    const int nwords = nch * NWV;
+    // ---- the plan.  Which blocks this workgroup marches over, in which order, and where their band cells lie follows
+    // from the band plane alone, and a coast does not move: the plan is stored in device memory (steps and cell
+    // lists), and k_scan -- which rewrites the plane every call -- compares each word with the one it replaces and
+    // leaves the number of the last call that saw a difference.  A plan stored by that call or a later one is used as
+    // it is: no flags are read, nothing is planned, no list is built.
+    typedef const __attribute__((address_space(4))) int *cintp;
+    char *const plan_wg = job.plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
+    unsigned short *const plan_lists = (unsigned short *)(plan_wg + SB_PLAN_LIST_OFF);
+    const int plan_stored = ((cintp)plan_wg)[0], plan_nst = ((cintp)plan_wg)[1];
+    const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
+    const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)job.plan_gen <= plan_stored;      // uniform
+    auto load_plane = [&]() {
         u64 mine = 0;
         for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
             int f[8];
@@ -303,6 +319,11 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             const u64 b = __builtin_amdgcn_ballot_w64((mine >> c) & 1ull);
             if (lane == 0) s_bits[c * NWV + wv] = b;
         }
+    };
+    if (!cached) load_plane();
+    else {
+        if (tid < plan_nst) s_ent[tid] = ((const uint2 *)(plan_wg + SB_PLAN_ENT_OFF))[tid];      // (at most STRIP_SCHED < 1024 steps)
+        if (tid == 0) { s_misc[0] = plan_nst; s_misc[5] = plan_rb; s_misc[6] = plan_re; s_misc[8] = 0; }
     }
     // the zero column of the three tables (never written again) while the flags travel
     for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
@@ -310,7 +331,6 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     if (fold_stats) wave_total_shifted_store(pm, s_wpart);
     SB_T(14);                                            // plane, zero columns, the waves' partial sums
     __syncthreads();
-    const int nwords = nch * NWV;
     SB_T(11);                                            // flags -> plane, statistics
     // ---- prologue 2, WAVE 0 ALONE (the others wait at one barrier): this workgroup's share and the schedule of its first
     // round.  The unit of cost is a STAGED block (an active block or a neighbour of one): workgroup b takes the active
@@ -420,15 +440,45 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
         if (lane == 0) s_misc[0] = n_pad;
     };
-    if (wv == 0) {
-        make_prefix();
-        const int rb0 = act_before_staged((int)(((long long)blockIdx.x * (int)((unsigned)tot_packed >> 16)) / G));
-        const int re0 = act_before_staged((int)(((long long)(blockIdx.x + 1) * (int)((unsigned)tot_packed >> 16)) / G));
-        if (lane == 0) { s_misc[5] = rb0; s_misc[6] = re0; }
-        if (rb0 < re0) make_schedule(rb0, min(rb0 + STRIP_ROUND, re0));
+    if (!cached) {
+        if (wv == 0) {
+            make_prefix();
+            const int rb0 = act_before_staged((int)(((long long)blockIdx.x * (int)((unsigned)tot_packed >> 16)) / G));
+            const int re0 = act_before_staged((int)(((long long)(blockIdx.x + 1) * (int)((unsigned)tot_packed >> 16)) / G));
+            if (lane == 0) { s_misc[5] = rb0; s_misc[6] = re0; s_misc[0] = 0; }
+            if (rb0 < re0) make_schedule(rb0, min(rb0 + STRIP_ROUND, re0));
+            wave_sync();
+            // the plan goes to device memory: the steps, each query step with the number of its cell list (the lists
+            // themselves are written by the waves that query them); a share of several rounds, or of more query steps
+            // than a stored plan holds, is planned every call
+            const int nstv = __builtin_amdgcn_readfirstlane(s_misc[0]);
+            int nq = 0;
+            uint2 *eg = (uint2 *)(plan_wg + SB_PLAN_ENT_OFF);
+            for (int c0 = 0; c0 < nstv; c0 += SB_WAVE) {
+                const int i = c0 + lane;
+                uint2 v = s_ent[i < nstv ? i : 0];
+                const bool q = i < nstv && !(v.x & SCH_IDLE) && (v.x & ((v.x & SCH_DRAIN) ? SCH_Q1 : SCH_Q2)) != 0u;
+                const u64 m = __builtin_amdgcn_ballot_w64(q);
+                const int qi = nq + __popcll(m & ((1ull << lane) - 1ull));
+                nq += __popcll(m);
+                if (q) v.x |= (unsigned)(qi & (SB_PLAN_NQ - 1)) << SCH_QI_SHIFT;
+                if (i < nstv) { s_ent[i] = v; eg[i] = v; }
+            }
+            const bool ok = re0 - rb0 <= STRIP_ROUND && nq <= SB_PLAN_NQ;
+            if (lane == 0) {
+                int *h = (int *)plan_wg;
+                h[1] = nstv; h[2] = rb0; h[3] = re0;
+                h[0] = ok ? job.call_id : 0;
+                s_misc[8] = ok ? 1 : 0;
+            }
+        }
+        SB_T(12);                                        // wave 0: prefix, share, schedule; the others: nothing
+        __syncthreads();
     }
-    SB_T(12);                                            // wave 0: prefix, share, schedule; the others: nothing
-    __syncthreads();
+    const bool store_lists = __builtin_amdgcn_readfirstlane(s_misc[8]) != 0;
+    // the cell list of the next step's query, from the stored plan (one entry per lane of the eight querying waves)
+    unsigned qc = 0xffffu;
+    const unsigned qc_off = (unsigned)(min(wv, C / 2 - 1) * SB_WAVE + lane);
     const int r_begin = __builtin_amdgcn_readfirstlane(s_misc[5]), r_end = __builtin_amdgcn_readfirstlane(s_misc[6]);
 
     const bool fastx = g.nx > W + 2;                   // one conditional add wraps every column of a staged row
@@ -608,12 +658,22 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     };
 
     // S2, waves 0 ..: 64 entries of the list per wave: bisection for the radius, contrast, result
-    auto query = [&](int qpos, int strip, int jp, int buf) __attribute__((always_inline)) {
-        const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
-        const int e = wv * SB_WAVE + lane;
-        if (wv * SB_WAVE >= ncell) return;               // wave-uniform
-        const bool valid = e < ncell;
-        const unsigned code = s_cell[buf][valid ? e : 0];
+    auto query = [&](int qpos, int strip, int jp, int buf, unsigned qi) __attribute__((always_inline)) {
+        unsigned code;
+        bool valid;
+        if (cached) {                                    // uniform: the list of the stored plan (loaded one step ahead)
+            code = qc;
+            valid = code != 0xffffu;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+        } else {
+            const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
+            const int e = wv * SB_WAVE + lane;
+            valid = e < ncell;
+            code = s_cell[buf][valid ? e : 0];
+            if (!valid) code = 0xffffu;
+            if (store_lists) plan_lists[qi * (unsigned)(SW * C) + (unsigned)e] = (unsigned short)code;
+            if (wv * SB_WAVE >= ncell) return;           // wave-uniform
+        }
         const int lx = (int)(code & 31u), ly = (int)((code >> 5) & 15u);
         const int x = strip * SW + lx, y = (jp - 1) * C + ly;
         const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;     // (fewer than 2^31 cells: check_dims)
@@ -733,7 +793,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         // inner loop or a loop with an early exit: the compiler counts the loads in flight per program point, and only
         // straight-line rotation with the same loads on every path lets it wait for block i's loads alone while those
         // of blocks i + 1 and i + 2 stay in flight.  The set just consumed receives the loads of block i + 3.
-        auto step = [&](StripRegs<T, FLY> &R, unsigned &E, unsigned &J, int i, int buf) __attribute__((always_inline)) {
+        auto step = [&](StripRegs<T, FLY> &R, unsigned &E, unsigned &J, const unsigned &En, int i, int buf) __attribute__((always_inline)) {
             const unsigned ent = E, sj = J;
             entry(i + STRIP_DEPTH, E, J);                // (consumed by `issue` below: the read travels under S1)
             const int pos = (int)(ent & 0xffffu);
@@ -748,7 +808,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                     if (FLY && (fold_stats || job.ngath > 0)) { sd = s_sdr[0]; rr = s_sdr[1]; }
                 }
                 BandWords bwd;
-                const bool lister = qany && wv >= C / 2;
+                const bool lister = qany && wv >= C / 2 && !cached;
                 if (lister) bwd = band_issue(strip, jp - qoff);
                 SB_TF(17);                                // restart barrier, band words issued
                 if (tid == STRIP_NT - 1) s_misc[1 + (buf == 2 ? 0 : buf + 1)] = 0;   // the next step's list starts empty
@@ -765,7 +825,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 lds_barrier();
                 SB_T(3);                                 // barrier
 #if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
-                if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf);
+                if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf, (ent >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
 #endif
                 if (!drain && wv >= 5 && wv < 8) vertical(jp);
                 SB_T(4);                                 // S2
@@ -773,11 +833,13 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 acc[drain ? 5 : 6] += 1;
 #endif
             }
+            // (every wave, every step, like the loads of `issue`; without a stored plan the value is not used)
+            qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
         };
         for (int i = 0; i < nst; i += STRIP_DEPTH) {         // nst is a multiple of three
-            step(R0, E0, J0, i, 0);
-            step(R1, E1, J1, i + 1, 1);
-            step(R2, E2, J2, i + 2, 2);
+            step(R0, E0, J0, E1, i, 0);
+            step(R1, E1, J1, E2, i + 1, 1);
+            step(R2, E2, J2, E0, i + 2, 2);
         }
         __syncthreads();                                 // the schedule and the ring are free for the next round
     }
@@ -787,6 +849,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // global-memory search; everything it needs comes from the job's copy in device memory ----
     if (s_misc[4] != 0) {                                // (uniform: read behind the round's last barrier)
         const DiagJob<T> &cj = *job.cold;
+        if (cached) { load_plane(); __syncthreads(); }   // (a stored plan: the plane was not needed so far)
         if (wv == 0) make_prefix();                      // the prefix array again (the cell lists lay over it)
         __syncthreads();
         tot_packed = s_misc[7];
@@ -867,6 +930,7 @@ static StripJob<T> strip_job(const DiagJob<T> &job) {
     s.fold_partials = job.fold_partials; s.gath = job.gath;
     s.seg_list = job.seg_list; s.seg_count = job.seg_count;
     s.cold = job.self;
+    s.plan = job.plan; s.plan_gen = job.plan_gen; s.call_id = job.call_id; s.plan_use = job.plan_use;
     s.stamps = job.stamps;
     return s;
 }

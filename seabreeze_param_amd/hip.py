@@ -101,6 +101,10 @@ class Context:
         """k_prep's work inside the contrast kernel (default) or as a kernel of its own (measurement / test knob)."""
         self._chk(self.lib.sb_set_fold(self.h, C.c_int(1 if on else 0)), "sb_set_fold")
 
+    def set_plan_cache(self, on: bool):
+        """The strip kernel keeps its plan while the band plane stands (default) or plans every call (measurement / test knob)."""
+        self._chk(self.lib.sb_set_plan_cache(self.h, C.c_int(1 if on else 0)), "sb_set_plan_cache")
+
     def set_static_sigma(self, on: bool):
         """Opt-in: sigma does not change between calls; its statistics are formed once (include/seabreeze_hip.h)."""
         self._chk(self.lib.sb_set_static_sigma(self.h, C.c_int(1 if on else 0)), "sb_set_static_sigma")

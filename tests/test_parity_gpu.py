@@ -133,17 +133,22 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, contrast_variant):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[(16, True), (16, False), (24, False)], ids=["strip", "strip-kprep", "tiles-halo24"])
+@pytest.fixture(params=[(16, True, True), (16, True, False), (16, False, True), (24, False, True)],
+                ids=["strip", "strip-replan", "strip-kprep", "tiles-halo24"])
 def contrast_variant(request, hipctx):
     """The contrast kernels the oracle comparisons run under: the marching-strip kernel (radius hints up to 16) doing
-    k_prep's work itself (the default for host-model calls on one domain) or with k_prep as a kernel of its own, and
-    the tile kernel with its 24-cell halo (what a radius hint of 17..24 selects).  Results never depend on the choice."""
-    hint, fold = request.param
+    k_prep's work itself (the default for host-model calls on one domain) -- with the plan of its march kept from call
+    to call (the default: the first call of a test plans, the later ones march by the stored plan) or made afresh every
+    call -- or with k_prep as a kernel of its own, and the tile kernel with its 24-cell halo (what a radius hint of
+    17..24 selects).  Results never depend on the choice."""
+    hint, fold, keep = request.param
     hipctx.set_search_radius_hint(hint)
     hipctx.set_fold(fold)
+    hipctx.set_plan_cache(keep)
     yield hint
     hipctx.set_search_radius_hint(16)
     hipctx.set_fold(True)
+    hipctx.set_plan_cache(True)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -173,6 +178,41 @@ def test_generic_flavour_fp64(hipctx, oracles, shape, bnd, contrast_variant):
         assert np.array_equal(sh[3] != 0, so[3] != 0)
     off = np.abs(cdist) > 180.0
     assert np.all(sh[3][off] == 0.0) and all(np.all(a[off] == 3.25) for a in sh[:3])
+
+
+@pytest.mark.parametrize("flavour", ["generic", "f2py"])
+def test_stored_plan_follows_the_planes(hipctx, oracles, flavour):
+    """The strip kernel marches by the plan an earlier call stored for as long as k_scan finds the band plane (f2py
+    flavour: and the land-side plane, whose bit at the last longitude the stored cell lists carry) unchanged: calls
+    that repeat the coast distance, shift its band, flip its sign (same band, other classes), widen the band by
+    maxdist and come back to the first one all match the oracle, call by call."""
+    nx, ny, nz = 256, 192, 2
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt, fractional_coast=(flavour == "f2py"))
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    base = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=700.0)
+    hipctx.set_search_radius_hint(16)
+    p = synth.pressure_1d(nz, dt) if flavour == "f2py" else synth.pressure_3d(st, nz, dt)
+    n = 4 if flavour == "generic" else 3
+    so, sh = _states(ny, nx, dt, n), _states(ny, nx, dt, n)
+    flipped = np.where(np.abs(base) < 12000.0, -base, base)
+    seq = [(base, 180.0), (base, 180.0), (np.roll(base, 7, axis=1), 180.0), (np.roll(base, 7, axis=1), 180.0),
+           (flipped, 180.0), (flipped, 180.0), (base, 300.0), (base, 300.0), (base, 180.0), (base, 180.0)]
+    for tn, (cd, maxdist) in enumerate(seq, start=1):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        if flavour == "f2py":
+            oo = orc.diag(tn, p, st.z, st.sigma, th, v, u, cd, *so, maxdist=maxdist, timestep=90.0)
+            oh = hipctx.diag(tn, p, st.z, st.sigma, th, v, u, cd, *sh, maxdist=maxdist, timestep=90.0)
+            for k, nm in enumerate(("sb_con", "t0", "windspeed", "winddir")):
+                _assert_close64(oh[k, :-1], oo[k, :-1], f"call {tn} {nm}")
+        else:
+            cdm = cd.copy()
+            cdm[np.abs(cdm) > maxdist] = 12000.0          # the host model's distance field holds the fill beyond maxdist
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdm, st.z, st.sigma, *so, halo=0, bnd=1)
+            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdm, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+            _assert_close64(a, b, f"{flavour} call {tn} state {nm}")
 
 
 @pytest.mark.parametrize("shape", [(96, 72, 3), (256, 192, 2)])
