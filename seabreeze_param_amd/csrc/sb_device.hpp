@@ -229,12 +229,12 @@ struct SbSegEntry {
     uint32_t seg, pad;
 };
 // the strip kernel's plan, per workgroup: 16 ints (call that stored it or 0, steps, first and last rank of its share),
-// the steps (8 bytes each), the cell lists of up to SB_PLAN_NQ query steps (8 x 64 codes of 16 bits, 0xffff: none)
+// the steps (8 bytes each), the cell lists of up to SB_PLAN_NQ query steps (8 x 64 entries of 32 bits, all ones: none)
 #define SB_PLAN_SCHED 384
 #define SB_PLAN_NQ 64
 #define SB_PLAN_ENT_OFF 64
 #define SB_PLAN_LIST_OFF (SB_PLAN_ENT_OFF + 8 * SB_PLAN_SCHED)
-#define SB_PLAN_STRIDE (SB_PLAN_LIST_OFF + 1024 * SB_PLAN_NQ)
+#define SB_PLAN_STRIDE (SB_PLAN_LIST_OFF + 2048 * SB_PLAN_NQ)
 #define SB_SEG_PARTS 64              // k_prep workgroups that compact the segment list, one sub-list each
 
 template <typename T>

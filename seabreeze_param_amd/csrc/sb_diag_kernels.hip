@@ -177,7 +177,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     // next wait sit out those stores as well (loads and stores share the in-order vmcnt counter).
     struct Trip {
         T sg[SPT], mk[SPT], ws[SPT], wd[SPT];
-        uint64_t ob[SPT], oc[SPT];                           // the band (f2py flavour: and land-side) word the call before left
+        uint64_t ob[SPT], oc[SPT];                           // the band and land-side words the call before left
         unsigned Y[SPT], W[SPT];
     };
     bool plane_changed = false;
@@ -194,8 +194,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
             const unsigned idx = in ? Yc * nxh + (unsigned)X : 0u;
             t.mk[q] = job.mask[job.mask_off + (in ? Yc * (unsigned)job.mask_ld + (unsigned)X : 0u)];
             t.ob[q] = job.bandbits[seg < nseg ? seg : 0u];
-            t.oc[q] = 0;
-            if (wrapper) t.oc[q] = job.clsbits[seg < nseg ? seg : 0u];
+            t.oc[q] = job.clsbits[seg < nseg ? seg : 0u];
             t.sg[q] = T(0); t.ws[q] = T(0); t.wd[q] = T(0);
             if (do_stats) t.sg[q] = job.sigma[idx];                      // wave-uniform condition
             if (wrapper) {                                               // wave-uniform condition
@@ -231,9 +230,9 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 job.clsbits[seg] = wc;
                 job.bandbits[seg] = wb;
             }
-            // the strip kernel's plan stands while the band plane does (f2py flavour: its cell lists also carry the
-            // land-side bit of the last longitude)
-            plane_changed |= t.ob[q] != wb || (wrapper && t.oc[q] != wc);
+            // the strip kernel's plan stands while both planes do (where the band cells lie; the radius of every cell's
+            // window, the land-side cells in it and its own class)
+            plane_changed |= t.ob[q] != wb || t.oc[q] != wc;
             if (wb) {                                            // wave-uniform
                 // the tile columns the segment's band cells fall in (two of 32 cells, three when the ghost
                 // width is not a multiple of the tile width): lane j looks at the bits of column tA + j

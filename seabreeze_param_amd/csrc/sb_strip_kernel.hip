@@ -48,15 +48,13 @@
 
 typedef unsigned long long u64;
 
+// Diagnostic build (-DSB_STAMPS: `make stamps`, tools/stamp_strip.py): every wave leaves the 100 MHz wall clock at a few
+// marks -- one scalar clock read and one exec-masked store each, no registers held (an earlier version summed shader
+// clocks per phase in 32 registers per lane: the spills that caused distorted what it measured).
 #ifdef SB_STAMPS
-#define SB_T(i) do { const long long t_now = clock64(); acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define SB_T(i) do { if (lane == 0) job.stamps[(size_t)(blockIdx.x * (STRIP_NT / SB_WAVE) + wv) * SB_NSTAMP + (i)] = wall_clock64(); } while (0)
 #else
 #define SB_T(i) do { } while (0)
-#endif
-#ifdef SB_STAMPS_FINE             // (stamps inside S1: each costs the wave some 700 cycles -- shares only)
-#define SB_TF(i) SB_T(i)
-#else
-#define SB_TF(i) do { } while (0)
 #endif
 
 // The fp64 constants of a staged row -- the logistic's argument reduction and Taylor coefficients, the fixed-point
@@ -258,11 +256,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     const int npos = job.ntx * npad;
     const unsigned npad_magic = 0xffffffffu / (unsigned)npad + 1u;       // floor(p / npad) = umulhi(p, magic) for p < 2^16
 
-#ifdef SB_STAMPS
-    long long acc[SB_NSTAMP], t_last = clock64();
-    const long long w_begin = wall_clock64();
-    for (int i = 0; i < SB_NSTAMP; ++i) acc[i] = 0;
-#endif
+    SB_T(0);                                             // start
     // ---- prologue 1: the flags k_scan raised, 1024 at a time, as a bit plane (word c NWV + wv = ballot of chunk c) ----
     T sd = T(0), rr = T(0);
     Moments pm = moments_empty();
@@ -295,7 +289,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // it is: no flags are read, nothing is planned, no list is built.
     typedef const __attribute__((address_space(4))) int *cintp;
     char *const plan_wg = job.plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
-    unsigned short *const plan_lists = (unsigned short *)(plan_wg + SB_PLAN_LIST_OFF);
+    unsigned *const plan_lists = (unsigned *)(plan_wg + SB_PLAN_LIST_OFF);
     const int plan_stored = ((cintp)plan_wg)[0], plan_nst = ((cintp)plan_wg)[1];
     const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
     const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)job.plan_gen <= plan_stored;      // uniform
@@ -314,7 +308,6 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 mine |= (i < npos && f[j] != 0) ? 1ull << (base + j) : 0ull;
             }
         }
-        SB_T(13);                                        // flag loads returned
         for (int c = 0; c < nch; ++c) {
             const u64 b = __builtin_amdgcn_ballot_w64((mine >> c) & 1ull);
             if (lane == 0) s_bits[c * NWV + wv] = b;
@@ -329,9 +322,9 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
     if (tid == 0) s_misc[4] = 0;
     if (fold_stats) wave_total_shifted_store(pm, s_wpart);
-    SB_T(14);                                            // plane, zero columns, the waves' partial sums
+    SB_T(1);                                             // first barrier reached
     __syncthreads();
-    SB_T(11);                                            // flags -> plane, statistics
+    SB_T(2);                                             // ... passed
     // ---- prologue 2, WAVE 0 ALONE (the others wait at one barrier): this workgroup's share and the schedule of its first
     // round.  The unit of cost is a STAGED block (an active block or a neighbour of one): workgroup b takes the active
     // blocks that lie between the staged blocks of ranks b S / G and (b+1) S / G in strip-major order, so every
@@ -472,12 +465,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 s_misc[8] = ok ? 1 : 0;
             }
         }
-        SB_T(12);                                        // wave 0: prefix, share, schedule; the others: nothing
         __syncthreads();
+        SB_T(3);                                         // planned
     }
     const bool store_lists = __builtin_amdgcn_readfirstlane(s_misc[8]) != 0;
     // the cell list of the next step's query, from the stored plan (one entry per lane of the eight querying waves)
-    unsigned qc = 0xffffu;
+    unsigned qc = ~0u;
     const unsigned qc_off = (unsigned)(min(wv, C / 2 - 1) * SB_WAVE + lane);
     const int r_begin = __builtin_amdgcn_readfirstlane(s_misc[5]), r_end = __builtin_amdgcn_readfirstlane(s_misc[6]);
 
@@ -558,15 +551,17 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         if (lm == 0ull) sb_scan1_u64(qa);                // wave-uniform; ql is zero everywhere
         else if (lm == ~0ull) { sb_scan1_u64(qa); ql = qa; }
         else sb_scan2_u64(qa, ql);
-        // land-side cells up to and including the lane's: those of lanes 1 .. lane by mbcnt on the mask shifted down, lane 0's added
-        const u64 lm1 = lm >> 1;
-        const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm1, (unsigned)(lm & 1ull)));
         const unsigned slot = (unsigned)(jp * C + wv) & RM;
         const unsigned o = __umul24(slot, P) + lane + 1;
         sA[o] = qa;
         sL[o] = ql;
-        sC[o] = (unsigned short)cnt;
-        if (lane == 0) s_land[slot] = lm;
+        if (!cached) {                                   // (a stored plan knows every window's radius, count and class)
+            // land-side cells up to and including the lane's: those of lanes 1 .. lane by mbcnt on the mask shifted down, lane 0's added
+            const u64 lm1 = lm >> 1;
+            const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm1, (unsigned)(lm & 1ull)));
+            sC[o] = (unsigned short)cnt;
+            if (lane == 0) s_land[slot] = lm;
+        }
         if (ent & SCH_RESTART) {
             // the tables start afresh: the row above the first one reads as zero, the running totals start at zero
             if (wv == NWV - 1) {
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { carry += v[i]; tab[(h0 + i) * P] = carry; }
             }
-        } else {
+        } else if (!cached) {
             unsigned short *tab = sC + o;
             unsigned v[C];
 #pragma unroll
@@ -659,65 +654,86 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
 
     // S2, waves 0 ..: 64 entries of the list per wave: bisection for the radius, contrast, result
     auto query = [&](int qpos, int strip, int jp, int buf, unsigned qi) __attribute__((always_inline)) {
+        // A cell's entry in the stored plan: bits 0-8 row << 5 | column, bit 9 its own class, bits 10-14 the radius of its
+        // window (0: it outgrows the tables), bits 15-25 the land-side cells in it; all ones: no cell.  Radius, count
+        // and class follow from the land-side plane, which stands as long as the plan does (k_scan watches it too).
         unsigned code;
-        bool valid;
+        bool valid, found, own;
+        int nn, nl;
         if (cached) {                                    // uniform: the list of the stored plan (loaded one step ahead)
             code = qc;
-            valid = code != 0xffffu;
+            valid = code != ~0u;
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
-        } else {
+            nn = (int)((code >> 10) & 31u);
+            nl = (int)((code >> 15) & 2047u);
+            own = ((code >> 9) & 1u) != 0u;
+            found = valid && nn != 0;
+            nn = max(nn, 1);                             // (reads in bounds; the result is not used)
+        }
+        if (!cached) {
             const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
             const int e = wv * SB_WAVE + lane;
             valid = e < ncell;
             code = s_cell[buf][valid ? e : 0];
-            if (!valid) code = 0xffffu;
-            if (store_lists) plan_lists[qi * (unsigned)(SW * C) + (unsigned)e] = (unsigned short)code;
-            if (wv * SB_WAVE >= ncell) return;           // wave-uniform
+            if (wv * SB_WAVE >= ncell) {                 // wave-uniform
+                if (store_lists) plan_lists[qi * (unsigned)(SW * C) + (unsigned)e] = ~0u;
+                return;
+            }
         }
         const int lx = (int)(code & 31u), ly = (int)((code >> 5) & 15u);
         const int x = strip * SW + lx, y = (jp - 1) * C + ly;
         const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;     // (fewer than 2^31 cells: check_dims)
-        int lim = H;
-        if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));   // uniform branch
-        const int limc = max(lim, 1);
         const unsigned rho = (unsigned)(jp * C + ly);    // ring row of the cell
         const unsigned cx = (unsigned)(lx + H + 1);      // its table column
-        // land-side count of the square of radius rad: C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0),
-        // r0 = rho-rad-1, r1 = rho+rad, a0 = cx-rad-1, a1 = cx+rad
-        auto count = [&](int rad) __attribute__((always_inline)) {
-            const unsigned r1 = __umul24((rho + rad) & RM, P) + cx, r0 = __umul24((rho - rad - 1) & RM, P) + cx;
-            return (int)(unsigned short)((unsigned)sC[r1 + rad] - (unsigned)sC[r0 + rad] - (unsigned)sC[r1 - rad - 1] + (unsigned)sC[r0 - rad - 1]);
-        };
-        // Two rounds of independent probes -- radii 4, 8, 12, 16, then the three radii below the smallest of those that
-        // holds both classes: 28 reads in two LDS round trips, where a bisection makes 20 reads in five.  The march is
-        // bound by the length of its dependent chains, not by LDS issue.
-        int nl1[4];
+        if (!cached) {
+            int lim = H;
+            if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));   // uniform branch
+            const int limc = max(lim, 1);
+            // land-side count of the square of radius rad: C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0),
+            // r0 = rho-rad-1, r1 = rho+rad, a0 = cx-rad-1, a1 = cx+rad
+            auto count = [&](int rad) __attribute__((always_inline)) {
+                const unsigned r1 = __umul24((rho + rad) & RM, P) + cx, r0 = __umul24((rho - rad - 1) & RM, P) + cx;
+                return (int)(unsigned short)((unsigned)sC[r1 + rad] - (unsigned)sC[r0 + rad] - (unsigned)sC[r1 - rad - 1] + (unsigned)sC[r0 - rad - 1]);
+            };
+            // Two rounds of independent probes -- radii 4, 8, 12, 16, then the three radii below the smallest of those that
+            // holds both classes: 28 reads in two LDS round trips, where a bisection makes 20 reads in five.  The march is
+            // bound by the length of its dependent chains, not by LDS issue.
+            int nl1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) nl1[k] = count(limited ? min(4 * (k + 1), limc) : 4 * (k + 1));
-        int lo = 1, hi = limc, nl = 0;
-        bool got = false;
+            for (int k = 0; k < 4; ++k) nl1[k] = count(limited ? min(4 * (k + 1), limc) : 4 * (k + 1));
+            int lo = 1, hi = limc;
+            nl = 0;
+            bool got = false;
 #pragma unroll
-        for (int k = 3; k >= 0; --k) {
-            const int rad = limited ? min(4 * (k + 1), limc) : 4 * (k + 1);
-            const bool mixed = nl1[k] > 0 && nl1[k] < (2 * rad + 1) * (2 * rad + 1);
-            if (mixed) { hi = rad; nl = nl1[k]; got = true; }
-            else if (rad < hi) lo = max(lo, rad + 1);
+            for (int k = 3; k >= 0; --k) {
+                const int rad = limited ? min(4 * (k + 1), limc) : 4 * (k + 1);
+                const bool mixed = nl1[k] > 0 && nl1[k] < (2 * rad + 1) * (2 * rad + 1);
+                if (mixed) { hi = rad; nl = nl1[k]; got = true; }
+                else if (rad < hi) lo = max(lo, rad + 1);
+            }
+            found = valid && lim >= 1 && got;
+            if (!got) lo = max(1, hi - 3);                   // (probes in bounds; their results are not used)
+            int nl2[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) nl2[m] = count(min(lo + m, hi));
+#pragma unroll
+            for (int m = 2; m >= 0; --m) {
+                const int rad = lo + m;
+                if (rad < hi && nl2[m] > 0 && nl2[m] < (2 * rad + 1) * (2 * rad + 1)) { hi = rad; nl = nl2[m]; }
+            }
+            nn = hi;
+            // the cell's own class: the table's centre, except that the f2py boundary rule maps the centre of the window at
+            // the last longitude to column 1 (there the list entry carries the bit)   ref :182-186, seabreeze_diag_python.f90:202
+            const u64 ownw = s_land[rho & RM];
+            own = (code >> 10) & 1u ? ((code >> 9) & 1u) != 0u : ((ownw >> (lx + H)) & 1ull) != 0ull;
+            if (store_lists)
+                plan_lists[qi * (unsigned)(SW * C) + (unsigned)(wv * SB_WAVE + lane)] =
+                    valid ? (code & 511u) | (own ? 1u << 9 : 0u) | (found ? (unsigned)nn << 10 : 0u) | (unsigned)nl << 15 : ~0u;
         }
-        const bool found = valid && lim >= 1 && got;
-        if (!got) lo = max(1, hi - 3);                   // (probes in bounds; their results are not used)
-        int nl2[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) nl2[m] = count(min(lo + m, hi));
-#pragma unroll
-        for (int m = 2; m >= 0; --m) {
-            const int rad = lo + m;
-            if (rad < hi && nl2[m] > 0 && nl2[m] < (2 * rad + 1) * (2 * rad + 1)) { hi = rad; nl = nl2[m]; }
-        }
-        const int nn = hi, area = (2 * nn + 1) * (2 * nn + 1);
+        const int area = (2 * nn + 1) * (2 * nn + 1);
         const unsigned r1 = __umul24((rho + nn) & RM, P) + cx, r0 = __umul24((rho - nn - 1) & RM, P) + cx;
         const u64 l11 = sL[r1 + nn], l01 = sL[r0 + nn], l10 = sL[r1 - nn - 1], l00 = sL[r0 - nn - 1];
         const u64 q11 = sA[r1 + nn], q01 = sA[r0 + nn], q10 = sA[r1 - nn - 1], q00 = sA[r0 - nn - 1];
-        const u64 ownw = s_land[rho & RM];
         // exact: the tables wrap, the window sum does not; every cell of the window carries the fixed-point bias
         const long long RL = (long long)((l11 - l01) - (l10 - l00) - (u64)nl * SB_FIX_BIAS);
         const long long RS = (long long)((q11 - q01) - (q10 - q00) - (u64)area * SB_FIX_BIAS) - RL;      // sea side
@@ -727,9 +743,6 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         const double dnl = (double)nl, dns = (double)(area - nl);
         const double num = to_f64(RL) * dns - to_f64(RS) * dnl;
         const T contrast = (T)(num * sb_inv(dnl * dns) * 0x1p-40);
-        // the cell's own class: the table's centre, except that the f2py boundary rule maps the centre of the window at
-        // the last longitude to column 1 (there the list entry carries the bit)   ref :182-186, seabreeze_diag_python.f90:202
-        const bool own = (code >> 10) & 1u ? ((code >> 9) & 1u) != 0u : ((ownw >> (lx + H)) & 1ull) != 0ull;
         const T mul = own ? T(1) : T(-1);
         int nnmax = 0;
         if constexpr (WF) {
@@ -749,11 +762,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     };
 
     // k_scan's shifted sums added up in k_prep's order and turned into the sigmoid scalars -- two divisions and a square
-    // root in fp64, some 200 dependent instructions -- by the last wave alone, while the others issue the loads of the
-    // first blocks; everybody picks the scalars up behind the barrier that opens the first run.  Workgroup 0 publishes
+    // root in fp64, some 200 dependent instructions -- by the FIRST wave alone (the oldest wave of its SIMD has priority
+    // at issue: it comes through the code in front of the march in half the time the last one takes, and everybody
+    // waits for these scalars); all pick them up behind the barrier that opens the first run.  Workgroup 0 publishes
     // them (for the calls that reuse them: static sigma), with or without a share of the march.
     auto finish_stats = [&]() {
-        if (wv == NWV - 1) {
+        if (wv == 0) {
             const Moments m = moments_of_shifted(shift_c, block_total_shifted_finish<NWV>(s_wpart));
             T st4[4];
             sigmoid_scalars<T>(m, st4);
@@ -764,14 +778,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         }
     };
     if (fold_stats && r_begin >= r_end && blockIdx.x == 0) finish_stats();
-    SB_T(0);                                             // prologue
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
     for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
         if (ra > r_begin) {                              // (a further round: wave 0 plans it; the cell lists lay over the prefix array)
             if (wv == 0) { make_prefix(); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
             __syncthreads();
         }
-        if (fold_stats && ra == r_begin) finish_stats();
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
         if (nst == 0) break;
         // a step's entry travels in scalar registers from the step that issues its block's loads (three steps ahead)
@@ -781,12 +793,19 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             e = i < nst ? (unsigned)__builtin_amdgcn_readfirstlane((int)v.x) : (SCH_DRAIN | SCH_IDLE);
             j = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y);
         };
+        // The first three steps of a round are its warm-up steps: all they do is issue the loads of steps 3, 4, 5 -- here,
+        // ahead of the loop, so that the statistics below are finished while those loads travel.
         unsigned E0, J0, E1, J1, E2, J2;
-        entry(0, E0, J0); entry(1, E1, J1); entry(2, E2, J2);
+        SB_T(28);
+        entry(STRIP_DEPTH, E0, J0); entry(STRIP_DEPTH + 1, E1, J1); entry(STRIP_DEPTH + 2, E2, J2);
         StripRegs<T, FLY> R0, R1, R2;
-        R0.th = R1.th = R2.th = T(0); R0.zz = R1.zz = R2.zz = T(0); R0.sg = R1.sg = R2.sg = T(0);
-        R0.lw = R1.lw = R2.lw = 0u; R0.lbit = R1.lbit = R2.lbit = 0u;
-        SB_T(1);                                         // pick, schedule
+        SB_T(29);
+        issue(R0, J0);
+        SB_T(30);
+        issue(R1, J1); issue(R2, J2);
+        SB_T(31);
+        if (fold_stats && ra == r_begin) finish_stats();
+        SB_T(4);                                         // march begins
         // A step: S1 of block i (and the list of the band cells to query), barrier, S2 (sums along latitude || queries
         // of the block two up); a drain step (behind the last block of a run) has no block and queries the block one
         // up.  The three register sets take turns -- as three copies of the step in the loop body, not as a switch, an
@@ -795,13 +814,15 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         // of blocks i + 1 and i + 2 stay in flight.  The set just consumed receives the loads of block i + 3.
         auto step = [&](StripRegs<T, FLY> &R, unsigned &E, unsigned &J, const unsigned &En, int i, int buf) __attribute__((always_inline)) {
             const unsigned ent = E, sj = J;
+#ifdef SB_STAMPS
+            if (i < SB_NSTAMP - 5) SB_T(5 + i);          // step i begins (i >= 3)
+#endif
             entry(i + STRIP_DEPTH, E, J);                // (consumed by `issue` below: the read travels under S1)
             const int pos = (int)(ent & 0xffffu);
             const int strip = (int)(sj >> 16), jp = (int)(sj & 0xffffu);
             const bool drain = (ent & SCH_DRAIN) != 0, idle = (ent & SCH_IDLE) != 0;
             const int qoff = drain ? 1 : 2;
             const bool qany = (ent & (drain ? SCH_Q1 : SCH_Q2)) != 0;
-            SB_TF(16);                                    // entry decode
             if (!idle) {
                 if (ent & SCH_RESTART) {
                     lds_barrier();                                // the queries of the run before have left the ring
@@ -810,33 +831,26 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                 BandWords bwd;
                 const bool lister = qany && wv >= C / 2 && !cached;
                 if (lister) bwd = band_issue(strip, jp - qoff);
-                SB_TF(17);                                // restart barrier, band words issued
                 if (tid == STRIP_NT - 1) s_misc[1 + (buf == 2 ? 0 : buf + 1)] = 0;   // the next step's list starts empty
                 if (!drain) stage(R, ent, jp);
-                SB_TF(20);                                // stage: the rest (scans, LDS writes)
 #if !(defined(STRIP_EXP) && (STRIP_EXP & 8))
                 if (lister) list_cells(strip, jp - qoff, bwd, buf);
 #endif
             }
-            SB_TF(21);                                    // list of band cells
             issue(R, J);                                          // (the one place of this copy of the step that loads)
-            SB_T(2);                                     // S1 (incl. the wait for the block's loads)
             if (!idle) {
                 lds_barrier();
-                SB_T(3);                                 // barrier
 #if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
                 if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf, (ent >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
 #endif
                 if (!drain && wv >= 5 && wv < 8) vertical(jp);
-                SB_T(4);                                 // S2
-#ifdef SB_STAMPS
-                acc[drain ? 5 : 6] += 1;
-#endif
             }
-            // (every wave, every step, like the loads of `issue`; without a stored plan the value is not used)
-            qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
+            // (Under the uniform condition, although every other load of the march is unconditional: with this load on
+            // every path hipcc 7.2 emitted NO wait at all for the staged blocks' loads in the fp64 kernels -- the
+            // results then hang on timing.  tests/test_build.py checks the waits of every variant in the built library.)
+            if (cached) qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
         };
-        for (int i = 0; i < nst; i += STRIP_DEPTH) {         // nst is a multiple of three
+        for (int i = STRIP_DEPTH; i < nst; i += STRIP_DEPTH) {       // nst is a multiple of three
             step(R0, E0, J0, E1, i, 0);
             step(R1, E1, J1, E2, i + 1, 1);
             step(R2, E2, J2, E0, i + 2, 2);
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         __syncthreads();                                 // the schedule and the ring are free for the next round
     }
 
-    SB_T(7);                                             // round tail
+    SB_T(5);                                             // march done
     // ---- the marked cells (rare): every band cell of this workgroup's blocks that holds the mark takes the
     // global-memory search; everything it needs comes from the job's copy in device memory ----
     if (s_misc[4] != 0) {                                // (uniform: read behind the round's last barrier)
@@ -880,6 +894,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             if (nnmax > 1) atomicMax(&job.flags[pos], nnmax);
         }
     }
+    SB_T(6);                                             // marked cells done
     if (job.fold) {
         // ---- k_wind's segment lists (k_prep's work on single-domain host-model calls): sub-list `part` holds the
         // segments with band cells of its contiguous range of the band plane, in ascending order ----
@@ -902,16 +917,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             if (tid == 0) job.seg_count[part] = total;
         }
     }
-#ifdef SB_STAMPS
-    SB_T(8);                                             // segment lists
-    if (tid == 0) {
-        acc[9] = w_begin;
-        acc[10] = wall_clock64();
-        for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)blockIdx.x * SB_NSTAMP + i] = acc[i];
-    }
-    if (lane == 0 && blockIdx.x < 64)
-        for (int i = 0; i < SB_NSTAMP; ++i) job.stamps[(size_t)(1024 + blockIdx.x * NWV + wv) * SB_NSTAMP + i] = acc[i];
-#endif
+    SB_T(7);                                             // end
 }
 
 // the hot part of the job, by value; everything else the kernel reads -- rarely -- from the copy of the whole job that

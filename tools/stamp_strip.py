@@ -2,7 +2,7 @@
 
     SEABREEZE_HIP_LIB=$PWD/seabreeze_param_amd/libseabreeze_hip_stamps.so python tools/stamp_strip.py [nx ny nz]
 
-Every wave sums the shader clock over the phases of its steps (diagnostic build only).  Shares, not run time.
+Every wave leaves the 100 MHz wall clock at the marks of sb_strip_kernel.hip (diagnostic build only).
 """
 import ctypes as C
 import sys
@@ -25,32 +25,33 @@ state = [np.zeros((ny, nx), dt) for _ in range(4)]
 for tn in (1, 2, 3):
     ctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *state)
 NWG, NS, NWV = 256, 32, 16
-NROW = 1024 + 64 * NWV
+NROW = NWG * NWV
 buf = (C.c_longlong * (NROW * NS))()
 rc = ctx.lib.sb_debug_stamps(ctx.h, buf, C.c_int(NROW))
 assert rc == 0, rc
-allrows = np.frombuffer(buf, dtype=np.int64).reshape(NROW, NS)
-s = allrows[:NWG]
-names = ["prologue", "schedule", "S1 stage", "barrier", "S2", "-", "-", "round tail", "seg lists"]
-steps, drains = s[:, 6], s[:, 5]
-print(f"workgroups {NWG}: steps per workgroup min {steps.min()} mean {steps.mean():.2f} max {steps.max()}; drain passes mean {drains.mean():.2f}")
-tot = s[:, [0, 1, 2, 3, 4, 7, 8]].sum(axis=1)
-for i in (0, 1, 2, 3, 4, 7, 8):
-    print(f"  {names[i]:10s} thread 0: per workgroup mean {s[:, i].mean():9.0f} cyc ({100 * s[:, i].sum() / tot.sum():4.1f} %)"
-          + (f"   per pass {s[:, i].sum() / max(1, (steps + drains).sum()):7.0f}" if i in (2, 3, 4) else ""))
-print(f"  prologue split: flag loads returned {s[:, 13].mean():.0f}, plane + partial sums {s[:, 14].mean():.0f}, barrier {s[:, 11].mean():.0f}, "
-      f"prefix + share {s[:, 12].mean():.0f}, picks + schedule {s[:, 15].mean():.0f}, barrier + statistics + first entries {s[:, 1].mean():.0f}")
-print(f"  total cycles per workgroup mean {tot.mean():.0f} max {tot.max()}; wall (10 ns ticks): start spread "
-      f"{s[:, 9].max() - s[:, 9].min()}, life mean {np.mean(s[:, 10] - s[:, 9]):.0f} max {np.max(s[:, 10] - s[:, 9])}, "
-      f"kernel span {s[:, 10].max() - s[:, 9].min()}")
-pw = allrows[1024:1024 + 64 * NWV].reshape(64, NWV, NS).astype(np.float64)
-npass = np.maximum(pw[:, :, 5] + pw[:, :, 6], 1)
-print("  S1 split, cycles per pass (wave: decode, restart+band words, load wait, t0, scans+writes, list, issue):")
-for w in range(NWV):
-    m = [(pw[:, w, i] / npass[:, w]).mean() for i in (16, 17, 18, 19, 20, 21, 2)]
-    print(f"      {w:3d}  " + " ".join(f"{x:6.0f}" for x in m))
-print("  per wave, cycles per pass:  wave     S1   barrier     S2")
-for w in range(NWV):
-    m = [(pw[:, w, i] / npass[:, w]).mean() for i in (2, 3, 4)]
-    print(f"                              {w:3d}  " + " ".join(f"{x:7.0f}" for x in m))
+t = np.frombuffer(buf, dtype=np.int64).reshape(NWG, NWV, NS).astype(np.float64) / 100.0     # us
+t0 = t[:, :, 0].min()
+k_end = t[:, :, 7].max()
+print(f"kernel span (first wave's start to last wave's end) {k_end - t0:.2f} us; workgroup starts within {t[:, 0, 0].max() - t0:.2f} us")
+names = ["start", "first barrier reached", "... passed", "planned", "march begins", "march done", "marked cells done", "end"]
+print("marks, us after the kernel's first wave started; mean over workgroups [max]")
+for w in (0, 5, 8, 15):
+    row = []
+    for i in (0, 1, 2, 4, 5, 6, 7):
+        v = t[:, w, i] - t0
+        row.append(f"{names[i]} {v.mean():.2f} [{v.max():.2f}]")
+    print(f"  wave {w:2d}: " + "; ".join(row))
+for w in (0, 15):
+    print(f"  wave {w:2d}: barrier passed -> round begins {np.mean(t[:, w, 28] - t[:, w, 2]):.2f}, entries read {np.mean(t[:, w, 29] - t[:, w, 28]):.2f}, "
+          f"first issue {np.mean(t[:, w, 30] - t[:, w, 29]):.2f}, two more {np.mean(t[:, w, 31] - t[:, w, 30]):.2f}, statistics {np.mean(t[:, w, 4] - t[:, w, 31]):.2f}")
+# steps: time between the beginnings of consecutive steps, wave 0, by step number
+print("step i begins -> step i + 1 begins, us (wave 0 | wave 15), mean over the workgroups that have the step")
+for i in range(0, NS - 9):
+    a, b = t[:, :, 8 + i], t[:, :, 9 + i]
+    ok = (b > a) & (a >= t[:, :, 4]) & (b <= t[:, :, 5] + 1e-9)
+    if ok[:, 0].sum() == 0:
+        break
+    print(f"   step {i:2d}: n {int(ok[:, 0].sum()):3d}   {np.mean((b - a)[:, 0][ok[:, 0]]):.2f} | {np.mean((b - a)[:, 15][ok[:, 15]]) if ok[:, 15].any() else float('nan'):.2f}")
+life = t[:, :, 7].max(axis=1) - t[:, :, 0].min(axis=1)
+print(f"workgroup life: mean {life.mean():.2f} max {life.max():.2f} min {life.min():.2f} us; march (wave 0) mean {np.mean(t[:, 0, 5] - t[:, 0, 4]):.2f} max {np.max(t[:, 0, 5] - t[:, 0, 4]):.2f}")
 print(ctx.last_counters())
