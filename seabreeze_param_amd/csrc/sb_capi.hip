@@ -1069,6 +1069,12 @@ int sb_set_search_radius_hint(sb_ctx *c, int radius) {
 
 #ifdef SB_STAMPS
 // diagnostic build only: the per-workgroup clock sums of the last k_thc3 launch
+int sb_debug_plan(sb_ctx *c, void *host, long long bytes) {      // the strip kernel's stored plan (diagnostic build)
+    if (!c || !host || !c->plan.p || bytes < 0 || (size_t)bytes > c->plan.cap) return SB_ERR_ARG;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(host, c->plan.p, (size_t)bytes, hipMemcpyDeviceToHost));
+    return SB_OK;
+}
 int sb_debug_stamps(sb_ctx *c, long long *host, int nwg) {
     if (!c || !host || !c->stamps.p) return SB_ERR_ARG;
     HIPCHK(c, hipDeviceSynchronize());

@@ -177,11 +177,18 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     // next wait sit out those stores as well (loads and stores share the in-order vmcnt counter).
     struct Trip {
         T sg[SPT], mk[SPT], ws[SPT], wd[SPT];
-        uint64_t ob[SPT], oc[SPT];                           // the band and land-side words the call before left
+        uint64_t old;                                        // lanes 2q, 2q + 1: the band and the land-side word the call before
+                                                             // left for segment q of the trip (one load for all of them)
         unsigned Y[SPT], W[SPT];
     };
     bool plane_changed = false;
+    static_assert(2 * SPT <= SB_WAVE, "two lanes per segment of a trip");
     auto issue = [&](unsigned s0, Trip &t) {
+        {
+            const unsigned seg = s0 + (unsigned)(lane >> 1) * nwaves;
+            const uint64_t *plane = (lane & 1) ? job.clsbits : job.bandbits;
+            t.old = plane[(lane < 2 * SPT && seg < nseg) ? seg : 0u];
+        }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const unsigned seg = s0 + q * nwaves;
@@ -193,8 +200,6 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
             const bool interior = in && xi >= 0 && xi < g.nx && yi >= 0 && yi < g.ny;
             const unsigned idx = in ? Yc * nxh + (unsigned)X : 0u;
             t.mk[q] = job.mask[job.mask_off + (in ? Yc * (unsigned)job.mask_ld + (unsigned)X : 0u)];
-            t.ob[q] = job.bandbits[seg < nseg ? seg : 0u];
-            t.oc[q] = job.clsbits[seg < nseg ? seg : 0u];
             t.sg[q] = T(0); t.ws[q] = T(0); t.wd[q] = T(0);
             if (do_stats) t.sg[q] = job.sigma[idx];                      // wave-uniform condition
             if (wrapper) {                                               // wave-uniform condition
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
         }
     };
     auto process = [&](unsigned s0, const Trip &t) {
+        uint64_t now = t.old;                                // (lanes 2q, 2q + 1: the words this call writes for segment q)
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const unsigned seg = s0 + q * nwaves;
@@ -230,9 +236,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 job.clsbits[seg] = wc;
                 job.bandbits[seg] = wb;
             }
-            // the strip kernel's plan stands while both planes do (where the band cells lie; the radius of every cell's
-            // window, the land-side cells in it and its own class)
-            plane_changed |= t.ob[q] != wb || t.oc[q] != wc;
+            if ((lane >> 1) == q) now = (lane & 1) ? wc : wb;
             if (wb) {                                            // wave-uniform
                 // the tile columns the segment's band cells fall in (two of 32 cells, three when the ghost
                 // width is not a multiple of the tile width): lane j looks at the bits of column tA + j
@@ -258,6 +262,9 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
                 }
             }
         }
+        // the strip kernel's plan stands while both planes do (where the band cells lie; the radius of every cell's
+        // window, the land-side cells in it and its own class)
+        plane_changed |= now != t.old;
     };
     // two register sets, alternating: the loads of trip n+1 are issued before trip n is used
     const unsigned step = SPT * nwaves;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
         process(s0, tb);
         s0 += step;
     }
-    if (plane_changed && lane == 0 && job.plan_gen) atomicMax(job.plan_gen, job.call_id);
+    if (plane_changed && job.plan_gen) atomicMax(job.plan_gen, job.call_id);
     if (!do_stats) return;
     // the workgroup's shifted sums (sb_device.hpp: merged by addition downstream, converted once at the end)
     __shared__ Moments wpart[STATS_NT / SB_WAVE];

@@ -326,30 +326,47 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     __syncthreads();
     SB_T(2);                                             // ... passed
     // ---- prologue 2, WAVE 0 ALONE (the others wait at one barrier): this workgroup's share and the schedule of its first
-    // round.  The unit of cost is a STAGED block (an active block or a neighbour of one): workgroup b takes the active
-    // blocks that lie between the staged blocks of ranks b S / G and (b+1) S / G in strip-major order, so every
-    // workgroup marches about S / G blocks (plus at most two where a run is cut) -- an equal share of ACTIVE blocks
-    // left the workgroup with the most short runs with 15 blocks against a mean of 10.
-    // Per word of the plane: active and staged blocks before it, packed (low / high 16 bits); the array lies where the
-    // cell lists of the march will (they are not in use while a round is planned).
+    // round.  Shares are equal in COST, in strip-major order.  The marks of tools/stamp_strip.py, fitted over the 256
+    // workgroups of the headline grid, give a workgroup's life as 1.25 us per staged block (an active block or a
+    // neighbour of one) + 0.56 us per active block (its band cells are queried) + 0.68 us per run (drain step, restart):
+    // weights 4 : 2 : 2.  Workgroup b takes the active blocks at which the running cost lies in [b, b + 1) T / G.  (An
+    // equal share of active blocks left the workgroup with the most short runs with 15 staged blocks against a mean of
+    // 10; an equal share of staged blocks still had lives of 20 .. 30 us around a mean of 25.)
+    // Per word of the plane: active and staged blocks before it, packed (low / high 16 bits) -- the array lies where
+    // the cell lists of the march will (they are not in use while a round is planned) -- and the cost before it, where
+    // the first rows of the first table will (their zero column is written again behind the planning).
     unsigned *s_pre = (unsigned *)&s_cell[0][0];
+    unsigned *s_cost = (unsigned *)&sA[0];
+    constexpr int CW_STAGED = 4, CW_ACTIVE = 2, CW_RUN = 2;
     static_assert(sizeof(s_cell) >= sizeof(unsigned) * STRIP_MAXW, "the prefix array fits where the cell lists lie");
     auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };      // this wave's LDS writes have landed
     auto stage_word = [&](int k) -> u64 {                // staged = act | act << 1 | act >> 1 (virtual blocks separate the strips)
         const u64 a = s_bits[k], pv = k > 0 ? s_bits[k - 1] : 0ull, nx = k + 1 < nwords ? s_bits[k + 1] : 0ull;
         return a | (a << 1) | (pv >> 63) | (a >> 1) | (nx << 63);
     };
-    int tot_packed = 0;
-    auto make_prefix = [&]() {                           // one wave
-        int run = 0;
+    auto run_starts = [&](int k, u64 sw) -> u64 {        // staged blocks of word k whose predecessor is not staged
+        const u64 swp = k > 0 ? stage_word(k - 1) : 0ull;
+        return sw & ~((sw << 1) | (swp >> 63));
+    };
+    int tot_packed = 0, tot_cost = 0;
+    auto make_prefix = [&](bool with_cost) {             // one wave
+        int run = 0, crun = 0;
         for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
             const int k = k0 + lane;
-            const int v = k < nwords ? (int)((unsigned)__popcll(s_bits[k]) | (unsigned)__popcll(stage_word(k)) << 16) : 0;
+            const u64 a = k < nwords ? s_bits[k] : 0ull, sw = k < nwords ? stage_word(k) : 0ull;
+            const int v = (int)((unsigned)__popcll(a) | (unsigned)__popcll(sw) << 16);
             const int incl = sb_wave_scan_add(v);
             if (k < nwords) s_pre[k] = (unsigned)(run + incl - v);
             run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
+            if (with_cost) {
+                const int c = CW_STAGED * __popcll(sw) + CW_ACTIVE * __popcll(a) + CW_RUN * __popcll(k < nwords ? run_starts(k, sw) : 0ull);
+                const int cincl = sb_wave_scan_add(c);
+                if (k < nwords) s_cost[k] = (unsigned)(crun + cincl - c);
+                crun += __builtin_amdgcn_readlane(cincl, SB_WAVE - 1);
+            }
         }
         tot_packed = run;
+        tot_cost = crun;
         if (lane == 0) s_misc[7] = run;
         wave_sync();
     };
@@ -375,16 +392,25 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
         return __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(me)) - 1;
     };
-    // active blocks before the staged block of rank t (all of them if there is no such block)
-    auto act_before_staged = [&](int t) -> int {
-        const int nact = tot_packed & 0xffff, nstaged = (int)((unsigned)tot_packed >> 16);
-        if (t >= nstaged) return nact;
-        int n;
-        const int k = find_word(t, true, n);
-        if (k < 0) return nact;
-        const int bpos = nth_bit(sb_uniform64(stage_word(k)), n);
-        const u64 a = sb_uniform64(s_bits[k]);
-        return (int)(__builtin_amdgcn_readfirstlane((int)s_pre[k]) & 0xffff) + __popcll(a & ((1ull << bpos) - 1ull));
+    // active blocks in front of the position at which the running cost reaches t (all of them beyond the total)
+    auto act_before_cost = [&](int t) -> int {
+        const int nact = tot_packed & 0xffff;
+        if (t >= tot_cost) return nact;
+        for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
+            const int k = k0 + lane;
+            const int lo = k < nwords ? (int)s_cost[k] : 0x7fffffff, up = k + 1 < nwords ? (int)s_cost[k + 1] : tot_cost;
+            const u64 hit = __builtin_amdgcn_ballot_w64(k < nwords && lo <= t && t < up);
+            if (hit) {                                   // wave-uniform: the word in which the cost crosses t
+                const int src = __ffsll((unsigned long long)hit) - 1, kk = k0 + src;
+                const u64 a = sb_uniform64(s_bits[kk]), sw = sb_uniform64(stage_word(kk)), rs = sb_uniform64(run_starts(kk, stage_word(kk)));
+                const u64 upto = lane == 63 ? ~0ull : (1ull << (lane + 1)) - 1ull;       // bits 0 .. lane
+                const int cum = __builtin_amdgcn_readlane(lo, src) + CW_STAGED * __popcll(sw & upto) + CW_ACTIVE * __popcll(a & upto) + CW_RUN * __popcll(rs & upto);
+                const u64 over = __builtin_amdgcn_ballot_w64(cum > t);
+                const int bpos = over ? __ffsll((unsigned long long)over) - 1 : 63;       // the first position behind the crossing
+                return (int)(__builtin_amdgcn_readfirstlane((int)s_pre[kk]) & 0xffff) + __popcll(a & ((1ull << bpos) - 1ull));
+            }
+        }
+        return nact;
     };
     // The schedule of the round that holds the active blocks of ranks [ra, rb): the staged positions in ascending
     // order with their flags, a drain step behind every run, three warm-up steps in front (they stage nothing and only
@@ -435,9 +461,9 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     };
     if (!cached) {
         if (wv == 0) {
-            make_prefix();
-            const int rb0 = act_before_staged((int)(((long long)blockIdx.x * (int)((unsigned)tot_packed >> 16)) / G));
-            const int re0 = act_before_staged((int)(((long long)(blockIdx.x + 1) * (int)((unsigned)tot_packed >> 16)) / G));
+            make_prefix(true);
+            const int rb0 = act_before_cost((int)(((long long)blockIdx.x * tot_cost) / G));
+            const int re0 = blockIdx.x + 1 == (unsigned)G ? (tot_packed & 0xffff) : act_before_cost((int)(((long long)(blockIdx.x + 1) * tot_cost) / G));
             if (lane == 0) { s_misc[5] = rb0; s_misc[6] = re0; s_misc[0] = 0; }
             if (rb0 < re0) make_schedule(rb0, min(rb0 + STRIP_ROUND, re0));
             wave_sync();
@@ -466,6 +492,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
             }
         }
         __syncthreads();
+        if (tid < 8) sA[tid * P] = 0;                    // (the cost array lay over the first rows' zero column)
         SB_T(3);                                         // planned
     }
     const bool store_lists = __builtin_amdgcn_readfirstlane(s_misc[8]) != 0;
@@ -781,7 +808,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
     for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
         if (ra > r_begin) {                              // (a further round: wave 0 plans it; the cell lists lay over the prefix array)
-            if (wv == 0) { make_prefix(); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
+            if (wv == 0) { make_prefix(false); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
             __syncthreads();
         }
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
@@ -864,7 +891,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     if (s_misc[4] != 0) {                                // (uniform: read behind the round's last barrier)
         const DiagJob<T> &cj = *job.cold;
         if (cached) { load_plane(); __syncthreads(); }   // (a stored plan: the plane was not needed so far)
-        if (wv == 0) make_prefix();                      // the prefix array again (the cell lists lay over it)
+        if (wv == 0) make_prefix(false);                 // the prefix array again (the cell lists lay over it)
         __syncthreads();
         tot_packed = s_misc[7];
         for (int r = r_begin; r < r_end; ++r) {

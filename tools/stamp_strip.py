@@ -54,4 +54,35 @@ for i in range(0, NS - 9):
     print(f"   step {i:2d}: n {int(ok[:, 0].sum()):3d}   {np.mean((b - a)[:, 0][ok[:, 0]]):.2f} | {np.mean((b - a)[:, 15][ok[:, 15]]) if ok[:, 15].any() else float('nan'):.2f}")
 life = t[:, :, 7].max(axis=1) - t[:, :, 0].min(axis=1)
 print(f"workgroup life: mean {life.mean():.2f} max {life.max():.2f} min {life.min():.2f} us; march (wave 0) mean {np.mean(t[:, 0, 5] - t[:, 0, 4]):.2f} max {np.max(t[:, 0, 5] - t[:, 0, 4]):.2f}")
+# what a workgroup's life is made of: its steps by kind, from the stored plan; least squares
+STRIDE, ENT_OFF = 3136 + 2048 * 64, 64
+raw = (C.c_ubyte * (64 + NWG * STRIDE))()
+if hasattr(ctx.lib, "sb_debug_plan") and ctx.lib.sb_debug_plan(ctx.h, raw, C.c_longlong(len(raw))) == 0:
+    plan = np.frombuffer(raw, dtype=np.uint8)[64:].reshape(NWG, STRIDE)
+    hdr = plan[:, :16].copy().view(np.int32)
+    rows = []
+    for b in range(NWG):
+        n = int(hdr[b, 1])
+        e = plan[b, ENT_OFF:ENT_OFF + 8 * n].copy().view(np.uint32).reshape(n, 2)[3:, 0]
+        idle, drain = (e >> 20) & 1, (e >> 18) & 1
+        q = np.where(drain == 1, (e >> 19) & 1, (e >> 16) & 1) * (1 - idle)
+        rows.append([1.0, np.sum((1 - drain) * (1 - idle)), np.sum(q), np.sum(drain * (1 - idle)), np.sum((e >> 17) & 1 * (1 - idle)), np.sum(idle)])
+    A = np.array(rows)
+    coef, *_ = np.linalg.lstsq(A, life, rcond=None)
+    print("life ~ %.2f + %.2f staged + %.2f queried + %.2f drain + %.2f run + %.2f padding   (us; residual rms %.2f)"
+          % (*coef, float(np.sqrt(np.mean((A @ coef - life) ** 2)))))
+    np.save("gpurun_out/plan_head.npy", plan[:, :3136].copy())
+    order = np.argsort(life)
+    print("  the five shortest and the five longest lives: workgroup, life, fitted, [staged queried drains runs padding], cells queried")
+    ncell = []
+    for b in range(NWG):
+        lists = plan[b, 3136:3136 + 2048 * 64].copy().view(np.uint32).reshape(64, 512)
+        ncell.append(int(np.sum(lists[:int(A[b, 2])] != 0xffffffff)))
+    for b in list(order[:5]) + list(order[-5:]):
+        print(f"     {b:4d} {life[b]:6.2f} {float(A[b] @ coef):6.2f} {A[b, 1:].astype(int).tolist()} {ncell[b]}")
+    A2 = np.column_stack([A, np.array(ncell) / 64.0])
+    c2, *_ = np.linalg.lstsq(A2, life, rcond=None)
+    print("  with the number of 64-cell query passes as a sixth term: %s residual rms %.2f" % (np.round(c2, 2).tolist(), float(np.sqrt(np.mean((A2 @ c2 - life) ** 2)))))
+    print("per workgroup: staged mean %.2f max %d; queried mean %.2f max %d; drains mean %.2f max %d; runs mean %.2f max %d"
+          % (A[:, 1].mean(), A[:, 1].max(), A[:, 2].mean(), A[:, 2].max(), A[:, 3].mean(), A[:, 3].max(), A[:, 4].mean(), A[:, 4].max()))
 print(ctx.last_counters())
