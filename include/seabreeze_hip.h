@@ -94,6 +94,11 @@ int  sb_set_fold(sb_ctx *ctx, int on);
    difference makes the kernel plan afresh (on, the default).  Off: it plans every call.  A measurement and test
    knob: results never depend on it.                                                                       */
 int  sb_set_plan_cache(sb_ctx *ctx, int on);
+/* A band step (sb_band_seabreeze_diag_*_dev, or a diag call with gathered moments in use) on the strip kernel runs
+   k_scan and k_wind ahead of the join with the communication stream and lets the contrast kernel apply the update
+   (0, the default), or k_scan | join | contrast kernel, k_wind -- the three kernels of a single-domain call, one
+   launch less, but less work to cover the communication with (1).  A measurement knob: results never depend on it.  */
+int  sb_set_band_order(sb_ctx *ctx, int contrast_first);
 /* Opt-in, off by default: the caller states that sigma (the sub-grid orography deviation, an ancillary that a
    host model reads once; ref: generic/sea_breeze_diag.f90:159-166 recomputes its mean and deviation every
    call) does not change between calls.  The first complete diag / band step after the switch forms the

@@ -57,6 +57,7 @@ struct sb_ctx {
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
     int no_plan_cache = 0;              // sb_set_plan_cache(ctx, 0): the strip kernel plans its march afresh every call
+    int band_late_wind = 0;             // sb_set_band_order(ctx, 1): a band step runs the contrast before k_wind (measurement)
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
     int stats_ngathered = 0;            // bands whose moments the kept scalars were merged from (0: this domain's own)
@@ -69,6 +70,7 @@ struct sb_ctx {
     int plan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const void *plan_bits = nullptr;
     int call_seq = 0, plan_use = 0;
+    bool segs_built = false;            // the last complete call's strip kernel compacted k_wind's segment lists
     int tiles_n = 0, tiles_strip = -1, flag_parity = 0;   // two alternating [tile flags | counters] buffers in `tiles`
     int *last_flags = nullptr;          // the buffer the last diag call used
     Moments *partials = nullptr;
@@ -213,18 +215,23 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.seg_list = (SbSegEntry *)c->seg_list.p;
     job.seg_count = c->seg_count;
     job.seg_cap = (int)seg_cap;
-    // this call's wind speed / direction at band cells: only a band step needs them (k_wind -> k_thc3)
+    // the host-model flavour derives t0 inside k_thc3; the f2py flavour returns the t0 plane
+    job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
+    // Whole single-domain calls run the contrast first and let k_wind apply the update.  A band step runs k_scan and
+    // k_wind ahead of the join with the communication stream and applies the update in the contrast kernel.  (The
+    // single-domain order in a band step -- k_scan | join | contrast, k_wind: six launches instead of seven -- was
+    // measured and is slower: only k_scan's 12 us then cover the 25 us of the communication stream's small kernels,
+    // 69.5 against 55.5 us for a 2560 x 240 x 56 band step; profiles/r03_band_step_cost.log.  sb_set_band_order.)
+    const bool late_wind = c->band_late_wind && c->gathered && strip && job.t0_fly && !c->no_fold;
+    job.wind_final = ((phases == 3 && !c->gathered) || late_wind) ? 1 : 0;
+    // this call's wind speed / direction at band cells, where k_wind runs ahead of the contrast (k_wind -> k_thc3)
     job.nws = job.nwd = nullptr;
-    if (!(phases == 3 && !c->gathered)) {
+    if (!job.wind_final) {
         if ((rc = ensure(c, c->nws, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         if ((rc = ensure(c, c->nwd, (size_t)g.nx * g.ny * sizeof(T)))) return rc;
         job.nws = (T *)c->nws.p;
         job.nwd = (T *)c->nwd.p;
     }
-    // the host-model flavour derives t0 inside k_thc3; the f2py flavour returns the t0 plane
-    job.t0_fly = (job.flavour == SB_FLAVOUR_GENERIC) ? 1 : 0;
-    // whole single-domain calls: contrast first, k_wind applies the update
-    job.wind_final = (phases == 3 && !c->gathered) ? 1 : 0;
     // the t0 plane with its ghost cells: f2py flavour only (k_t0 -> k_thc3)
     job.t0 = nullptr;
     if (!job.t0_fly) {
@@ -233,7 +240,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     if ((rc = ensure(c, c->jobcopy, sizeof(DiagJob<double>)))) return rc;
     job.self = (DiagJob<T> *)c->jobcopy.p;
-    job.plan = nullptr; job.plan_gen = nullptr; job.call_id = 0; job.plan_use = 0;
+    job.plan = nullptr; job.plan_gen = nullptr; job.call_id = 0; job.plan_use = 0; job.seg_trust = 0;
     if (strip) {
         const size_t need = 64 + (size_t)c->ncu * SB_PLAN_STRIDE;
         if (c->plan.cap < need) {
@@ -282,6 +289,8 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
     lc.no_fold = c->no_fold != 0;
+    const bool strip_folds = strip && job.t0_fly && !c->no_fold;
+    lc.segs_stand = strip_folds && c->gathered && c->plan_use && c->segs_built && !c->no_plan_cache;
     job.no_prefetch = 1;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     job.gath = nullptr; job.ngath = 0;
@@ -291,6 +300,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     HIPCHK(c, sb_launch_diag<T>(job, Hk, lc));
     c->rep_launches += launched;
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
+    c->segs_built = strip_folds;
     if (c->static_sigma && c->host_depth == 0 && !lc.reuse_stats) {
         c->stats_valid = true;
         c->stats_sigma = (const void *)job.sigma;
@@ -1446,6 +1456,12 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
 int sb_set_fold(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     c->no_fold = on ? 0 : 1;
+    return SB_OK;
+}
+
+int sb_set_band_order(sb_ctx *c, int contrast_first) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->band_late_wind = contrast_first ? 1 : 0;
     return SB_OK;
 }
 

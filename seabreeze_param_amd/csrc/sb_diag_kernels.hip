@@ -489,8 +489,12 @@ __device__ __forceinline__ T sb_ld(const T *p) {
     else return *p;
 }
 
-template <typename T, int UN, bool FINAL>
+// MODE 0: the winds go to scratch planes (a band step, ahead of the contrast kernel); 1: ... and the update is applied
+// (single domain: the contrast kernel ran first); 2: no walk -- the winds of an earlier MODE 0 launch and the contrast
+// the strip kernel has left in thc since are read back and the update applied (a band step's last, small kernel)
+template <typename T, int UN, int MODE>
 __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T> job) {
+    constexpr bool FINAL = MODE != 0;
     const Geo g = job.g;
     const int lane = threadIdx.x & 63;
     // clear the other tile-flag buffer for the next call (this call's was read by k_prep)
@@ -518,19 +522,20 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
             if (a < best) { best = a; lev1 = k; }
         }
     }
-    if (gw >= total) return;
-    SbSegEntry ent = entry(gw);
-    for (int e = gw; e < total; e += nwaves) {
-        const SbSegEntry cur = ent;
-        if (e + nwaves < total) ent = entry(e + nwaves);          // the next entry travels under this one's walk
+    // one aligned 64-cell segment: its band lanes walk their column
+    auto segment = [&](const SbSegEntry cur) __attribute__((always_inline)) {
         const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
         const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
-        if (!((cur.word >> lane) & 1ull)) continue;               // band bits are set for interior cells of processed rows only
+        if (!((cur.word >> lane) & 1ull)) return;               // band bits are set for interior cells of processed rows only
         const size_t o = (size_t)y * g.nx + x;
         // the final update's inputs: issued ahead of the column walk
         T n_thc = T(0), ws_old = T(0), wd_old = T(0);
         if constexpr (FINAL) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
         int lev = lev1;
+        if constexpr (MODE == 2) {
+            sb_trigger_update<T, false>(job, o, n_thc, SbCellState<T>{job.nws[o], job.nwd[o], ws_old, wd_old});
+            return;
+        }
         if (job.flavour == SB_FLAVOUR_GENERIC && job.level_rule == 0) {
             // whole batches of UN levels in flight; the last batch is padded by re-reading level
             // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
@@ -590,6 +595,25 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
             job.nws[o] = n_ws;
             job.nwd[o] = n_wd;
         }
+    };
+    // The lists of the call before (a band step whose planning of the march stands: no k_prep in this call) hold as long
+    // as k_scan found both planes unchanged; if it did not -- once per change of the coast -- the waves take the
+    // segments of the plane itself in turn: unbalanced, correct.
+    if (job.seg_trust && *job.plan_gen >= job.call_id) {
+        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
+        for (unsigned sg = (unsigned)gw; sg < nseg; sg += (unsigned)nwaves) {
+            SbSegEntry cur;
+            cur.word = job.bandbits[sg]; cur.seg = sg; cur.pad = 0;
+            if (cur.word) segment(cur);                           // wave-uniform
+        }
+        return;
+    }
+    if (gw >= total) return;
+    SbSegEntry ent = entry(gw);
+    for (int e = gw; e < total; e += nwaves) {
+        const SbSegEntry cur = ent;
+        if (e + nwaves < total) ent = entry(e + nwaves);          // the next entry travels under this one's walk
+        segment(cur);
     }
 }
 
@@ -631,8 +655,15 @@ static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool
 template <typename T>
 static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
     const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
-    if (job.wind_final) hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, true>), wg, wb, 0, st, job);
-    else hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, false>), wg, wb, 0, st, job);
+    if (job.wind_final) hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 1>), wg, wb, 0, st, job);
+    else hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 0>), wg, wb, 0, st, job);
+}
+
+// the update of a band step on the strip kernel: thc holds this call's contrast, the scratch planes its winds
+template <typename T>
+static void launch_update(const DiagJob<T> &job, int ncu, hipStream_t st) {
+    const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
+    hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 2>), wg, wb, 0, st, job);
 }
 
 // event pair k of a profiled call brackets kernel k (SB_PROF_*); pairs of kernels a call does not launch stay unrecorded
@@ -656,14 +687,16 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     hipError_t e = hipSuccess;
     int nl = 0;                                                  // kernels enqueued
     const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
-    int nblk = (int)((nseg + 79) / 80);                          // 16 waves x 5 segments per trip
+    int nblk = (int)((nseg + 31) / 32);                          // 16 waves x one trip of 2 segments: a small domain (a band of
+                                                                 // a multi-GPU run) is spread over all CUs, its waves make few
+                                                                 // dependent trips -- k_scan is latency, not bytes, there
     if (nblk < 1) nblk = 1;
     if (nblk > lc.ncu) nblk = lc.ncu;                            // one 1024-thread workgroup per CU, two trips of loads in flight
     const dim3 pg(2 + SB_SEG_PARTS), pb(PREP_NT);
     // Single-domain calls run the contrast first and let k_wind apply the thresholds and the state update
     // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there the contrast
     // kernel applies them.
-    if (job.wind_final && ph1 && ph2) {
+    if (job.wind_final && ph1 && ph2 && !gathered) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
@@ -703,6 +736,28 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if (lc.launches) *lc.launches += nl;
         return hipGetLastError();
     }
+    // ---- a band step on the strip kernel: k_scan ahead of the join; behind it the contrast -- it merges the moments
+    // gathered from all ranks and compacts k_wind's segment lists itself -- and k_wind with the update: the three
+    // kernels of a single-domain call
+    if (job.wind_final) {
+        if (ph1) {
+            launch_scan<T>(job, nblk, lc.partials, false, st);
+            ++nl;
+        }
+        if (ph2) {
+            DiagJob<T> fj = job;
+            fj.fold = 1;
+            fj.fold_partials = nullptr;
+            fj.fold_nparts = 0;
+            if (gathered && !reuse) { fj.gath = lc.gathered; fj.ngath = lc.ngathered; }
+            fj.stats_out = (T *)lc.stats;
+            if ((e = launch_contrast<T>(fj, H, lc.ncu, st)) != hipSuccess) return e;
+            launch_wind<T>(job, lc.ncu, st);
+            nl += 2;
+        }
+        if (lc.launches) *lc.launches += nl;
+        return hipGetLastError();
+    }
     // ---- phase 1: needs neither theta's ghost cells nor the statistics of the other bands ---------
     if (ph1) {
         // a band step takes this band's own sigma moments from the same pass (lc.moments_out), publishes
@@ -711,16 +766,22 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, own_stats, st);
         SB_EV_END(SB_PROF_SCAN);
-        SB_EV_BEGIN(SB_PROF_PREP);
-        hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats ? nblk : 0, (T *)lc.stats,
-                           gathered ? lc.moments_out : (Moments *)nullptr);
-        SB_EV_END(SB_PROF_PREP);
+        const bool lists_stand = lc.segs_stand && !own_stats;
+        if (!lists_stand) {
+            SB_EV_BEGIN(SB_PROF_PREP);
+            hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats ? nblk : 0, (T *)lc.stats,
+                               gathered ? lc.moments_out : (Moments *)nullptr);
+            SB_EV_END(SB_PROF_PREP);
+            ++nl;
+        }
         if (own_stats && gathered && lc.moments_out && lc.moments_event &&
             (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
+        DiagJob<T> wj = job;
+        wj.seg_trust = lists_stand ? 1 : 0;
         SB_EV_BEGIN(SB_PROF_WIND);
-        launch_wind<T>(job, lc.ncu, st);
+        launch_wind<T>(wj, lc.ncu, st);
         SB_EV_END(SB_PROF_WIND);
-        nl += 3;
+        nl += 2;
     }
     // ---- phase 2: statistics of all bands, theta with its ghost cells -------------------------
     if (ph2) {
@@ -741,10 +802,19 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             SB_EV_END(SB_PROF_T0);
             ++nl;
         }
+        // (the strip kernel leaves the contrast in thc whatever the order: a loop that loads a cell's winds and state
+        // next to the prefetched blocks of the march drains them at every step; the update is a kernel of its own)
+        if (job.strip) {
+            pj.wind_final = 1;
+            // ... and compacts the segment lists: this call's update kernel reads them, and the next call's k_wind
+            // if the planes stand (no k_prep then)
+            if (job.t0_fly && !lc.no_fold) { pj.fold = 1; pj.fold_partials = nullptr; pj.fold_nparts = 0; if (!pj.stats_out) pj.stats_out = (T *)lc.stats; }
+        }
         SB_EV_BEGIN(SB_PROF_THC);
         if ((e = launch_contrast<T>(pj, H, lc.ncu, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
         ++nl;
+        if (job.strip) { launch_update<T>(job, lc.ncu, st); ++nl; }
     }
     if (lc.launches) *lc.launches += nl;
     return hipGetLastError();

@@ -33,6 +33,8 @@ struct SbLaunchCtx {
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
     bool reuse_stats;               // the sigmoid scalars in `stats` stand (static sigma): no moments, no merge
     bool no_fold;                   // keep k_prep as a kernel of its own (sb_set_fold(ctx, 0): measurement and tests)
+    bool segs_stand;                // band step on the strip kernel: the segment lists of the call before are in place
+                                    // (same geometry; k_wind checks on the device that the planes did not change): no k_prep
     int *launches;                  // += kernels enqueued by the call, or nullptr
 };
 

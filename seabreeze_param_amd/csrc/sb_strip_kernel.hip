@@ -225,7 +225,9 @@ template <> __device__ __forceinline__ float strip_mark<float>() { return __uint
 __device__ __forceinline__ bool strip_is_mark(double v) { return __double_as_longlong(v) == 0x7ff85ea5b4ee2e00ll; }
 __device__ __forceinline__ bool strip_is_mark(float v) { return __float_as_uint(v) == 0x7fc5ea5bu; }
 
-template <typename T, bool FLY, bool WF>     // FLY: t0 from theta, z, sigma while staging; WF: k_wind applies the update
+// FLY: t0 from theta, z, sigma while staging.  The contrast goes to thc; thresholds and state update are k_wind's (a
+// cell's winds and state loaded here, next to the prefetched blocks of the march, would drain them at every step).
+template <typename T, bool FLY>
 __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
     constexpr int RM = STRIP_RING - 1;
@@ -772,15 +774,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
         const T contrast = (T)(num * sb_inv(dnl * dns) * 0x1p-40);
         const T mul = own ? T(1) : T(-1);
         int nnmax = 0;
-        if constexpr (WF) {
-            if (found) { nnmax = nn; job.thc[o] = mul * contrast; }          // ref :216; k_wind applies :235-266
-        } else {
-            if (found) {
-                nnmax = nn;
-                const DiagJob<T> &cj = *(const DiagJob<T> *)job.cold;
-                sb_trigger_update<T>(cj, (size_t)o, mul * contrast, sb_trigger_load<T>(cj, (size_t)o));     // ref :216, :235-266
-            }
-        }
+        if (found) { nnmax = nn; job.thc[o] = mul * contrast; }              // ref :216; k_wind applies :235-266
         // cells whose window outgrows the tables: marked, handled behind the march
         if (valid && !found) { job.thc[o] = strip_mark<T>(); s_misc[4] = 1; }
         // per-block largest radius (diagnostic, read by sb_last_counters); the flag k_scan raised is 1
@@ -913,8 +907,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
                         atomicAdd(&cj.counters[0], 1);
                         if (one_class) atomicAdd(&cj.counters[1], 1);
                         const T mulg = sb_bit(cj.clsbits, g.nw, x + g.h, y + g.h) ? T(1) : T(-1);
-                        if constexpr (WF) job.thc[o] = mulg * cg;
-                        else sb_trigger_update<T>(cj, (size_t)o, mulg * cg, sb_trigger_load<T>(cj, (size_t)o));
+                        job.thc[o] = mulg * cg;
                     }
                 }
             }
@@ -972,10 +965,9 @@ template <typename T>
 hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st) {
     const dim3 gr(ncu), bl(STRIP_NT);                   // one persistent workgroup per CU
     const StripJob<T> sj = strip_job<T>(job);
-    if (job.t0_fly && job.wind_final) hipLaunchKernelGGL((k_strip<T, true, true>), gr, bl, 0, st, ncu, sj);
-    else if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true, false>), gr, bl, 0, st, ncu, sj);
-    else if (job.wind_final) hipLaunchKernelGGL((k_strip<T, false, true>), gr, bl, 0, st, ncu, sj);
-    else hipLaunchKernelGGL((k_strip<T, false, false>), gr, bl, 0, st, ncu, sj);
+    if (!job.wind_final) return hipErrorInvalidValue;   // (the update is k_wind's: sb_launch_diag sees to it)
+    if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true>), gr, bl, 0, st, ncu, sj);
+    else hipLaunchKernelGGL((k_strip<T, false>), gr, bl, 0, st, ncu, sj);
     return hipGetLastError();
 }
 template hipError_t sb_launch_strip<float>(const DiagJob<float> &, int, hipStream_t);

@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.sb_version()
 
 
+def test_strip_kernels_wait_for_their_prefetched_blocks():
+    """The march of k_strip keeps three blocks of loads in flight; where the compiler puts the s_waitcnt vmcnt(N) for
+    them has gone wrong silently twice (N collapsing to 0..2; no wait at all): tools/check_waits.py reads the
+    disassembly of the built library and wants three waits at full depth in every variant."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_waits", os.path.join(ROOT, "tools", "check_waits.py"))
+    cw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cw)
+    if not os.path.exists(cw.OBJDUMP):
+        pytest.skip("no llvm-objdump in this image")
+    waits = cw.strip_kernel_waits(hip.LIB_PATH if hasattr(hip, "LIB_PATH") else os.path.join(ROOT, "seabreeze_param_amd", "libseabreeze_hip.so"))
+    assert len(waits) == 4, sorted(waits)                 # float / double x t0 on the fly or from the plane
+    for name, hist in waits.items():
+        need = cw.expected_depth(name)
+        assert sum(v for k, v in hist.items() if k >= need) >= 3, (name, sorted(hist.items()))
+
+
 def test_no_device_means_loud_failure():
     from conftest import gpu_visible
     if gpu_visible():

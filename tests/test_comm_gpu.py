@@ -49,9 +49,10 @@ def test_swap_bounds_single_rank(dtype, with_comm):
         ctx.close()
 
 
+@pytest.mark.parametrize("contrast_first", [False, True], ids=["wind-first", "contrast-first"])
 @pytest.mark.parametrize("static_sigma", [False, True], ids=["default", "static-sigma"])
 @pytest.mark.parametrize("with_comm", [False, True])
-def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
+def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma, contrast_first):
     """sb_band_seabreeze_diag_*_dev with one band owning the globe: the ghost frame it fills itself
     (poles replicate, longitude wraps) must give the single-domain SB_BND_GLOBAL result, and the
     fork/join with the communication stream must order correctly over several steps."""
@@ -69,6 +70,7 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
             ctx.comm_init(hip.comm_unique_id(), 0, 1)
         ctx.set_search_radius_hint(h)
         ctx.set_static_sigma(static_sigma)
+        ctx.set_band_order(contrast_first)
         stream = torch.cuda.current_stream().cuda_stream
         reports = []
 
@@ -98,10 +100,68 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma):
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
         # what a band step enqueues (one rank: the all-gather is a 40-byte copy, no neighbours to send to):
         # on the communication stream k_stats + its merge, the copy, the ghost fill; on the caller's k_scan, k_prep, k_wind,
-        # k_thc3 (which merges the gathered moments itself); with static sigma the statistics and the copy go
-        assert reports[0] == dict(kernel_launches=7, rccl_ops=0, rccl_groups=0, d2d_copies=1)
-        later = dict(kernel_launches=5, rccl_ops=0, rccl_groups=0, d2d_copies=0) if static_sigma else reports[0]
+        # the strip kernel (which merges the gathered moments itself) and the update; with static sigma the statistics
+        # and the copy go.  With the contrast kernel ahead of k_wind (sb_set_band_order) k_prep and the update go too.
+        n0 = 6 if contrast_first else 8
+        assert reports[0] == dict(kernel_launches=n0, rccl_ops=0, rccl_groups=0, d2d_copies=1)
+        n1 = n0 if contrast_first else n0 - 1            # (from the second step on the segment lists of the step before stand: no k_prep)
+        later = dict(kernel_launches=n1 - 2, rccl_ops=0, rccl_groups=0, d2d_copies=0) if static_sigma else dict(reports[0], kernel_launches=n1)
         assert all(r == later for r in reports[1:]), reports
+    finally:
+        ctx.close()
+
+
+def test_band_step_follows_a_changing_coast(oracles):
+    """From its second step on a band step runs no k_prep: k_wind takes the segment lists the strip kernel of the step
+    before compacted, unless k_scan finds the planes changed in this very step -- then its waves walk the plane itself.
+    Steps that repeat the coast distance, shift it and come back all match the single-domain oracle."""
+    from seabreeze_param_amd import synth
+    nx, ny, nz, h = 200, 96, 3, 6
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    base = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=900.0, kwin=h - 1)
+    base[np.abs(base) > 180.0] = 12000.0
+    p = synth.pressure_3d(st, nz, dt)
+    ctx = hip.Context(0)
+    try:
+        ctx.set_search_radius_hint(h)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def frame(a):
+            # (torch's current stream is the null stream here, for which the library substitutes a stream of its own --
+            # and torch brings its own copy of the HIP runtime: nothing orders the two, so every hand-over between
+            # torch and the library is a synchronisation on the side that wrote last)
+            f = torch.zeros((ny + 2 * h, nx + 2 * h), dtype=torch.float64, device="cuda")
+            f[h:h + ny, h:h + nx] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            torch.cuda.synchronize()
+            ctx.swap_bounds_dev(dt, f.data_ptr(), nx, ny, h, stream)
+            ctx.synchronize()
+            return f
+
+        z, sg = frame(st.z), frame(st.sigma)
+        mk = frame(base)                                   # one device array, rewritten in place: the planes' buffers stay
+        pd = torch.from_numpy(p).cuda()
+        state = [torch.zeros((ny, nx), dtype=torch.float64, device="cuda") for _ in range(4)]
+        ref = [np.zeros((ny, nx)) for _ in range(4)]
+        shifted = np.roll(base, 9, axis=1)
+        launches = []
+        for tn, cd in enumerate((base, base, shifted, shifted, base, base), start=1):
+            mk.copy_(frame(cd))
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            thf, ud, vd = frame(th), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+            torch.cuda.synchronize()
+            ctx.band_seabreeze_diag_dev(dt, 5400.0, tn, nx, ny, nz, h, pd.data_ptr(), ud.data_ptr(), vd.data_ptr(),
+                                        thf.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
+                                        *[s.data_ptr() for s in state], stream)
+            ctx.synchronize()
+            launches.append(ctx.last_step_report()["kernel_launches"])
+            orc.seabreeze_diag(5400.0, tn, p, u, v, th, cd, st.z, st.sigma, *ref, halo=0, bnd=1)
+            for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
+                err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
+                assert err < 1e-7, f"step {tn} {nm}: {err}"
+        assert launches == [8, 7, 7, 7, 7, 7], launches     # k_prep in the first step only
     finally:
         ctx.close()
 

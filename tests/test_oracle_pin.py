@@ -115,3 +115,49 @@ def test_generic_flavour_equals_wrapper_on_interior(oracles):
     assert np.array_equal(sw[2][band], sg[2][band])        # thc
     assert np.all(sg[3][~(np.abs(cdist) <= 180.0)] == 0.0) # generic fill, ref: generic/sea_breeze_diag.f90:176
     assert np.all(out[0][:-1][~band[:-1]] == np.float64(2.0e20))
+
+
+# ----------------------------------------------------------------------------------------
+# the host-model flavour against the reference's generic/sea_breeze_diag.f90 itself
+# ----------------------------------------------------------------------------------------
+def _generic_module():
+    import importlib.util
+    import os
+    from conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_golden_generic", os.path.join(GOLDEN, "make_golden_generic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("prec", PREC)
+def test_generic_flavour_winds_match_the_generic_file(oracles, prec):
+    """windspeed and winddir of the host-model flavour -- 3-D p with minloc over all levels, windspeed stored every call,
+    winddir on the first step and the target-time steps (ref: generic/sea_breeze_diag.f90:223-227, 235-239, 261-266) --
+    bit for bit what the reference's own generic file, compiled unmodified, returns at tn = 1, 2, 15 on a grid with an
+    open-ocean rim (tests/golden/make_golden_generic.py; live against oracle/_ref/libsb_refgen_r*.so where it is built).
+    thc and sb_con of that file cannot be pinned: its `found` flag is never initialised (ref :141),
+    and as compiled here not even the first band cell searches (`first_cell_searched` False, thc = 0/0 throughout) --
+    the window search is pinned through the f2py twin instead (test_oracle_matches_golden_diag, *_compiled_reference)."""
+    import os
+    from conftest import ROOT
+    m = _generic_module()
+    g = golden("generic_ref_96x72")
+    assert not bool(g["first_cell_searched"])
+    orc = oracles[prec]
+    dt = orc.dt
+    st, cdist, p, per_step = m.inputs(dt)
+    state = [np.zeros((m.NY, m.NX), dt) for _ in range(4)]
+    live = None
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", f"libsb_refgen_r{prec}.so")):
+        live = m.run_reference(prec)
+    for tn, u, v, th in per_step:
+        orc.seabreeze_diag(m.TIMESTEP, tn, p, u, v, th, cdist, st.z, st.sigma, *state, halo=0, bnd=1)
+        for nm, a in (("ws", state[0]), ("wd", state[1])):
+            key = f"{nm}_tn{tn}_r{prec}"
+            assert np.array_equal(a, g[key]), key
+            if live is not None:
+                assert np.array_equal(a, live[key]), "live " + key
+        band = np.abs(cdist) <= 180.0
+        assert band.any() and np.all(state[3][~band] == 0.0)                      # ref :176: 0.0 beyond maxdist
+        assert np.isfinite(state[2][band]).all()                                  # (the oracle searches at every cell)

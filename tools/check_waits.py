@@ -53,7 +53,7 @@ def strip_kernel_waits(lib):
 
 def expected_depth(name):
     """fly (t0 derived while staging: four loads a row) -> 8, else 4"""
-    m = re.match(r"_Z7k_stripI([fd])Lb([01])ELb([01])E", name)
+    m = re.match(r"_Z7k_stripI([fd])Lb([01])E", name)
     return 8 if m.group(2) == "1" else 4
 
 
