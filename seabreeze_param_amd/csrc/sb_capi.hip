@@ -92,7 +92,8 @@ struct sb_ctx {
     int prof_calls = 0, prof_max = 0;
     // latitude-band communicator (RCCL, loaded on demand by sb_comm_init)
     hipStream_t aux_stream = nullptr;   // communication of a band step runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mom = nullptr;
+    Moments *band_moments_out = nullptr;   // set around phase 1 of a band step: where k_scan leaves this band's moments
     DevBuf band_mom;                    // [5 own moments | 5 x nranks gathered]
     void *rccl_lib = nullptr;
     void *comm = nullptr;
@@ -241,6 +242,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->jobcopy, sizeof(DiagJob<double>)))) return rc;
     job.self = (DiagJob<T> *)c->jobcopy.p;
     job.plan = nullptr; job.plan_gen = nullptr; job.call_id = 0; job.plan_use = 0; job.seg_trust = 0;
+    job.moments_out = nullptr; job.stats_ticket = nullptr;
     if (strip) {
         const size_t need = 64 + (size_t)c->ncu * SB_PLAN_STRIDE;
         if (c->plan.cap < need) {
@@ -284,8 +286,9 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     }
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
-    lc.moments_out = nullptr;        // (a band step forms its moments with k_stats on the communication stream)
-    lc.moments_event = nullptr;
+    lc.moments_out = (phases == 1) ? c->band_moments_out : nullptr;   // (a band step: k_scan publishes this band's moments)
+    lc.moments_event = (phases == 1) ? c->ev_mom : nullptr;
+    lc.stats_ticket = (int *)c->ticket + 1;
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
     lc.no_fold = c->no_fold != 0;
@@ -381,6 +384,7 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
         HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_mom, hipEventDisableTiming));
     }
     if ((rc = ensure(c, c->band_mom, (size_t)5 * (c->nranks + 1) * sizeof(double)))) return rc;
     double *mine = (double *)c->band_mom.p, *gath = mine + 5;
@@ -392,24 +396,29 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     // static sigma (opt-in): the scalars of the first step stand, no moments, no all-gather, no merge
     const bool reuse = reuse_stats<T>(c, sigma, nx, ny, halo);
     c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;
-    // fork: everything that talks to the other ranks goes to the second stream, and starts at once.  This band's
-    // sigma moments are formed there by a small kernel pair of their own (k_stats, 5 MB at eight ranks) and gathered
-    // straight away, the ghost rows of theta follow (every rank issues the two RCCL operations in this order), while
-    // k_scan (without the statistics), k_prep and k_wind -- which need neither -- run on the caller's stream: the
-    // round trip of the all-gather is covered by them instead of starting only after k_scan and k_prep.
+    // fork: everything that talks to the other ranks goes to the second stream: the exchange of theta's ghost rows at
+    // once, the all-gather of the sigma moments as soon as k_scan has published this band's (every rank issues the two
+    // RCCL operations in this order), while k_scan and k_wind run on the caller's stream.
     hipError_t he = hipEventRecord(c->ev_fork, st);
     if (he == hipSuccess) he = hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0);
     if (he != hipSuccess) { c->gathered = saved_g; c->ngathered = saved_n; return hipfail(c, he, "band step fork"); }
-    rc = SB_OK;
-    if (!reuse) {
-        rc = sigma_moments_dev<T>(c, nx, ny, halo, sigma, mine, (void *)c->aux_stream);
-        if (!rc) { c->rep_launches += 2; rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream); }
-    }
-    if (!rc) rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream);
-    // (whatever happened on the way: the second stream is joined into the caller's again)
-    he = hipEventRecord(c->ev_join, c->aux_stream);
+    // The ghost rows of theta first: they depend on nothing this step computes.
+    rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream);
+    // Phase 1 on the caller's stream: k_scan -- whose last workgroup merges this band's sigma moments and leaves them for
+    // the all-gather (one rank: in the gathered set itself) -- then k_wind.  (The moments used to be formed by a kernel
+    // of their own on the communication stream; with the caller's stream filling every CU that kernel ran behind
+    // k_scan and k_wind, not beside them, and held the join up by 17 us: profiles/r03_band_step_cost.log.)
+    c->band_moments_out = reuse ? nullptr : (Moments *)(c->nranks == 1 ? gath : mine);
     if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
                                         thc, sb_con, tun, (void *)st, 1);
+    c->band_moments_out = nullptr;
+    if (!rc && !reuse && c->nranks > 1) {
+        he = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);          // (recorded behind k_scan by phase 1)
+        if (he != hipSuccess) rc = hipfail(c, he, "band step moments event");
+        if (!rc) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
+    }
+    // (whatever happened on the way: the second stream is joined into the caller's again)
+    he = hipEventRecord(c->ev_join, c->aux_stream);
     if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
     if (he != hipSuccess && !rc) rc = hipfail(c, he, "band step join");
     if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma,
@@ -766,7 +775,7 @@ int sigmoid_dev(sb_ctx *c, int nx, int ny, const T *ary, T *sm, void *stream) {
     if (nx < 1 || ny < 1 || !ary || !sm) return fail(c, SB_ERR_ARG, "bad sigmoid arguments");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->stats_valid = false;                 // the shared scalars now belong to `ary`, not to a diag call's sigma
-    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, (T *)c->stats, nullptr, st));
+    HIPCHK(c, sb_launch_stats<T>(ary, nx, ny, nx, 0, c->partials, (T *)c->stats, nullptr, (int *)c->ticket + 1, st));
     HIPCHK(c, sb_launch_sigmoid_apply<T>(ary, sm, (size_t)nx * ny, (const T *)c->stats, st));
     return SB_OK;
 }
@@ -792,7 +801,7 @@ int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, doubl
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const int nxh = nx + 2 * halo;
     HIPCHK(c, sb_launch_stats<T>(sigma, nx, ny, nxh, (size_t)halo * nxh + halo, c->partials, (T *)c->stats,
-                                 (Moments *)moments5, st));
+                                 (Moments *)moments5, (int *)c->ticket + 1, st));
     return SB_OK;
 }
 
@@ -961,12 +970,12 @@ int sb_create(sb_ctx **out, int device) {
         return hipfail(nullptr, e, "hipStreamCreate");
     }
     bool ok = hipMalloc((void **)&c->partials, SB_STATS_MAX_BLOCKS * sizeof(Moments)) == hipSuccess &&
-              hipMalloc((void **)&c->ticket, sizeof(unsigned int)) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, 2 * sizeof(unsigned int)) == hipSuccess &&     // [0] k_scan's spare word, [1] k_stats' ticket
               hipMalloc(&c->stats, 4 * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&c->counters, 2 * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&c->seg_count, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
               hipMemset(c->seg_count, 0, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
-              hipMemset(c->ticket, 0, sizeof(unsigned int)) == hipSuccess &&
+              hipMemset(c->ticket, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
               hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess &&
               hipDeviceSynchronize() == hipSuccess;   // the null-stream memsets have landed before any other stream runs
     if (!ok) {
@@ -985,6 +994,7 @@ int sb_destroy(sb_ctx *c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_mom) (void)hipEventDestroy(c->ev_mom);
     if (c->band_mom.p) (void)hipFree(c->band_mom.p);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);

@@ -279,6 +279,8 @@ struct DiagJob {
     int *plan_gen;                  // number of the last call whose band plane differed from that of the call before
     int call_id;                    // number of this call (> 0, ascending)
     int plan_use;                   // 1: a plan stored by a call no older than *plan_gen may be used
+    Moments *moments_out;           // band step: k_scan's last workgroup merges the partials and leaves this band's moments
+    int *stats_ticket;              //   here (for the all-gather); a device word that is zero between launches
     int seg_trust;                  // 1: k_wind's segment lists are those the strip kernel of the call before compacted;
                                     //    they stand unless k_scan found the planes changed in this call (*plan_gen == call_id)
     int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius

@@ -43,30 +43,14 @@ __device__ __forceinline__ Moments moments_from_shifted(double c, double s1, dou
     return acc;
 }
 
-// Workgroup partial -> global partials.  The cross-workgroup merge is a kernel of its own
-// (k_moments_final): an in-kernel ticket would need an agent-scope release per workgroup,
-// and in a kernel that also writes tens of MB (k_scan's fill) every such release drains
-// the XCD's dirty L2 -- measured 20 us for 512 workgroups, against ~2 us for the boundary.
+// Workgroup partial -> global partials.  For k_scan the cross-workgroup merge is the next kernel's business (the strip
+// kernel's prologue, or k_prep): an in-kernel ticket with an agent-scope release per workgroup drains the XCD's dirty
+// L2 every time, and k_scan writes tens of MB (the fill) -- measured 20 us for 512 workgroups, against ~2 us for a
+// kernel boundary.  k_stats, which writes nothing else, hands its partials over with write-through stores instead
+// (no release, nothing to drain) and merges them itself -- see there.
 __device__ __forceinline__ void store_partial(Moments acc, Moments *wpart, Moments *__restrict__ partials) {
     acc = block_merge(acc, wpart);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
-
-// One workgroup merges the partials in index order (a fixed tree: the result does not
-// depend on arrival order) and publishes either the moments themselves (band-local, for
-// the multi-GPU gather) or the sigmoid scalars.
-template <typename T>
-__global__ __launch_bounds__(STATS_NT) void k_moments_final(const Moments *__restrict__ partials, int nparts,
-                                                            T *__restrict__ stats,
-                                                            Moments *__restrict__ moments_out) {
-    __shared__ Moments wpart[STATS_NT / SB_WAVE];
-    Moments m = moments_empty();
-    for (int b = threadIdx.x; b < nparts; b += STATS_NT) m = moments_merge(m, partials[b]);
-    m = block_merge(m, wpart);
-    if (threadIdx.x == 0) {
-        if (moments_out) *moments_out = m;
-        else sigmoid_scalars<T>(m, stats);
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -76,9 +60,17 @@ __global__ __launch_bounds__(STATS_NT) void k_moments_final(const Moments *__res
 // pairwise (Chan) from there on.  Replaces the reference's two sequential passes
 // (ref: generic/sea_breeze_diag.f90:466-477).
 // ------------------------------------------------------------------------------------
+// The workgroup that arrives last merges the partials -- in index order, a fixed tree: the result does not depend on who is
+// last -- and publishes the moments (band-local, for the multi-GPU gather) or the sigmoid scalars: one launch, where a
+// merge kernel of its own used to follow (a band step's communication stream is a chain of such small launches).
+// Hand-over across workgroups (the per-XCD L2s are not coherent with each other; k_scan may be filling them with dirty
+// lines on another stream meanwhile, so no L2 write-back here): every partial is stored write-through (agent-scope
+// atomic stores) and drained before its workgroup draws a ticket; the last arriver reads them past its own caches
+// (agent-scope atomic loads).
 template <typename T>
 __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, int nx, int ny, int ld,
-                                                    size_t off0, Moments *__restrict__ partials) {
+                                                    size_t off0, Moments *__restrict__ partials, int *__restrict__ ticket,
+                                                    T *__restrict__ stats, Moments *__restrict__ moments_out) {
     const unsigned n = (unsigned)nx * (unsigned)ny;
     const unsigned stride = gridDim.x * STATS_NT;
     const bool flat = (ld == nx);
@@ -109,7 +101,37 @@ __global__ __launch_bounds__(STATS_NT) void k_stats(const T *__restrict__ ary, i
         }
     }
     __shared__ Moments wpart[STATS_NT / SB_WAVE];
-    store_partial(moments_from_shifted(c, s1, s2, mn, mx, cnt), wpart, partials);
+    __shared__ int s_last;
+    const Moments mine = block_merge(moments_from_shifted(c, s1, s2, mn, mx, cnt), wpart);
+    if (threadIdx.x == 0) {
+        double *dst = (double *)&partials[blockIdx.x];
+        const double v[5] = {mine.n, mine.mean, mine.m2, mine.mn, mine.mx};
+        static_assert(sizeof(Moments) == 5 * sizeof(double), "Moments is five doubles");
+        for (int i = 0; i < 5; ++i) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (int)gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    Moments m = moments_empty();
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += STATS_NT) {
+        const double *src = (const double *)&partials[b];
+        Moments o;
+        o.n = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o.mean = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o.m2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o.mn = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o.mx = __hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = moments_merge(m, o);
+    }
+    __syncthreads();                                     // (wpart is used again)
+    m = block_merge(m, wpart);
+    if (threadIdx.x == 0) {
+        if (moments_out) *moments_out = m;
+        else sigmoid_scalars<T>(m, stats);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (zeroed at creation; every launch leaves it zero)
+    }
 }
 
 // Merge the moments gathered from every latitude band (one entry per rank) and derive the
@@ -287,7 +309,40 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
     Moments t;
     t.n = (double)cnt; t.mean = s1; t.m2 = s2; t.mn = mn; t.mx = mx;
     t = block_total_shifted<STATS_NT / SB_WAVE>(t, wpart);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (!job.moments_out) {                              // the next kernel adds them up (strip kernel's prologue, k_prep)
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+        return;
+    }
+    // A band step: the moments of this band go to the all-gather as soon as they exist -- the last workgroup to arrive
+    // adds the partials up (k_prep's order: same bits) and publishes them.  Hand-over as in k_stats: write-through
+    // stores, drained, then the ticket; read past the caches.  (No agent-scope release: it would write back the L2's
+    // dirty lines, and this kernel has just written the fill values of most of its cells.)
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        double *dst = (double *)&partials[blockIdx.x];
+        const double v[5] = {t.n, t.mean, t.m2, t.mn, t.mx};
+        for (int i = 0; i < 5; ++i) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tk = __hip_atomic_fetch_add(job.stats_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = tk == (int)gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    Moments v = moments_empty();
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += STATS_NT) {
+        const double *src = (const double *)&partials[b];
+        v.n += __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.mean += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.m2 += __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.mn = fmin(v.mn, __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        v.mx = fmax(v.mx, __hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();                                     // (wpart is used again)
+    const Moments m = moments_of_shifted(c, block_total_shifted<STATS_NT / SB_WAVE>(v, wpart));
+    if (threadIdx.x == 0) {
+        *job.moments_out = m;
+        __hip_atomic_store(job.stats_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -622,14 +677,13 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
 // ------------------------------------------------------------------------------------
 template <typename T>
 hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials, T *stats,
-                           Moments *moments_out, hipStream_t st) {
+                           Moments *moments_out, int *ticket, hipStream_t st) {
     // one workgroup per CU, fewer when the field is small (8 elements per thread per trip)
     const size_t n = (size_t)nx * ny;
     int nblk = (int)((n + (size_t)STATS_NT * 8 - 1) / ((size_t)STATS_NT * 8));
     if (nblk < 1) nblk = 1;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL(k_stats<T>, dim3(nblk), dim3(STATS_NT), 0, st, ary, nx, ny, ld, off0, partials);
-    hipLaunchKernelGGL(k_moments_final<T>, dim3(1), dim3(STATS_NT), 0, st, partials, nblk, stats, moments_out);
+    hipLaunchKernelGGL(k_stats<T>, dim3(nblk), dim3(STATS_NT), 0, st, ary, nx, ny, ld, off0, partials, ticket, stats, moments_out);
     return hipGetLastError();
 }
 
@@ -741,7 +795,11 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     // kernels of a single-domain call
     if (job.wind_final) {
         if (ph1) {
-            launch_scan<T>(job, nblk, lc.partials, false, st);
+            const bool publish = gathered && lc.moments_out != nullptr && !reuse;     // this band's moments, for the all-gather
+            DiagJob<T> sj = job;
+            if (publish) { sj.moments_out = lc.moments_out; sj.stats_ticket = lc.stats_ticket; }
+            launch_scan<T>(sj, nblk, lc.partials, publish, st);
+            if (publish && lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
             ++nl;
         }
         if (ph2) {
@@ -763,19 +821,23 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         // a band step takes this band's own sigma moments from the same pass (lc.moments_out), publishes
         // them for the all-gather and signals the communication stream
         const bool own_stats = (!gathered || lc.moments_out != nullptr) && !reuse;
+        // (a band step: k_scan's last workgroup merges and publishes the moments itself -- the all-gather can start
+        // behind this one kernel)
+        const bool scan_publishes = own_stats && gathered && lc.moments_out != nullptr;
+        DiagJob<T> sj = job;
+        if (scan_publishes) { sj.moments_out = lc.moments_out; sj.stats_ticket = lc.stats_ticket; }
         SB_EV_BEGIN(SB_PROF_SCAN);
-        launch_scan<T>(job, nblk, lc.partials, own_stats, st);
+        launch_scan<T>(sj, nblk, lc.partials, own_stats, st);
         SB_EV_END(SB_PROF_SCAN);
-        const bool lists_stand = lc.segs_stand && !own_stats;
+        if (scan_publishes && lc.moments_event && (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
+        const bool lists_stand = lc.segs_stand;
         if (!lists_stand) {
             SB_EV_BEGIN(SB_PROF_PREP);
-            hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats ? nblk : 0, (T *)lc.stats,
-                               gathered ? lc.moments_out : (Moments *)nullptr);
+            hipLaunchKernelGGL(k_prep<T>, pg, pb, 0, st, job, (const Moments *)lc.partials, own_stats && !scan_publishes ? nblk : 0,
+                               (T *)lc.stats, (Moments *)nullptr);
             SB_EV_END(SB_PROF_PREP);
             ++nl;
         }
-        if (own_stats && gathered && lc.moments_out && lc.moments_event &&
-            (e = hipEventRecord(lc.moments_event, st)) != hipSuccess) return e;
         DiagJob<T> wj = job;
         wj.seg_trust = lists_stand ? 1 : 0;
         SB_EV_BEGIN(SB_PROF_WIND);
@@ -820,9 +882,9 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     return hipGetLastError();
 }
 
-template hipError_t sb_launch_stats<float>(const float *, int, int, int, size_t, Moments *, float *, Moments *,
+template hipError_t sb_launch_stats<float>(const float *, int, int, int, size_t, Moments *, float *, Moments *, int *,
                                            hipStream_t);
-template hipError_t sb_launch_stats<double>(const double *, int, int, int, size_t, Moments *, double *, Moments *,
+template hipError_t sb_launch_stats<double>(const double *, int, int, int, size_t, Moments *, double *, Moments *, int *,
                                             hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<float>(const float *, float *, size_t, const float *, hipStream_t);
 template hipError_t sb_launch_sigmoid_apply<double>(const double *, double *, size_t, const double *, hipStream_t);

@@ -26,8 +26,9 @@ struct SbLaunchCtx {
     void *stats;                    // sigmoid scalars (4 x T)
     const Moments *gathered;        // per-band sigma moments to merge instead of scanning sigma, or nullptr
     int ngathered;
-    Moments *moments_out;           // band step: k_scan's own moments go here (k_prep) ...
-    hipEvent_t moments_event;       // ... and this event is recorded behind them, or nullptr
+    Moments *moments_out;           // band step: this band's sigma moments go here (k_scan's last workgroup merges them) ...
+    hipEvent_t moments_event;       // ... and this event is recorded behind k_scan, or nullptr
+    int *stats_ticket;              // ... with this device word (zero between launches) as the workgroups' ticket
     int ncu;                        // compute units (k_scan and the contrast kernel run one workgroup per CU)
     int phases;                     // bit 0: k_scan + k_prep + k_wind (no ghost cells, no statistics needed);
                                     // bit 1: statistics of all bands, k_t0, k_thc3.  3 = the whole call
@@ -40,7 +41,8 @@ struct SbLaunchCtx {
 
 template <typename T>
 hipError_t sb_launch_stats(const T *ary, int nx, int ny, int ld, size_t off0, Moments *partials, T *stats,
-                           Moments *moments_out, hipStream_t st);   // moments_out: publish moments, not scalars
+                           Moments *moments_out, int *ticket, hipStream_t st);   // moments_out: publish moments, not scalars;
+                                                                                // ticket: a device word that is zero between launches
 template <typename T>
 hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats, hipStream_t st);
 template <typename T>

@@ -98,14 +98,13 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma, c
             for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
-        # what a band step enqueues (one rank: the all-gather is a 40-byte copy, no neighbours to send to):
-        # on the communication stream k_stats + its merge, the copy, the ghost fill; on the caller's k_scan, k_prep, k_wind,
-        # the strip kernel (which merges the gathered moments itself) and the update; with static sigma the statistics
-        # and the copy go.  With the contrast kernel ahead of k_wind (sb_set_band_order) k_prep and the update go too.
-        n0 = 6 if contrast_first else 8
-        assert reports[0] == dict(kernel_launches=n0, rccl_ops=0, rccl_groups=0, d2d_copies=1)
+        # what a band step enqueues (one rank: its moments are the gathered set, no neighbours to send to):
+        # on the communication stream the ghost fill; on the caller's k_scan (whose last workgroup publishes the band's moments), k_prep, k_wind,
+        # the strip kernel (which merges the gathered moments itself) and the update; with static sigma the statistics go.  With the contrast kernel ahead of k_wind (sb_set_band_order) k_prep and the update go too.
+        n0 = 4 if contrast_first else 6
+        assert reports[0] == dict(kernel_launches=n0, rccl_ops=0, rccl_groups=0, d2d_copies=0)
         n1 = n0 if contrast_first else n0 - 1            # (from the second step on the segment lists of the step before stand: no k_prep)
-        later = dict(kernel_launches=n1 - 2, rccl_ops=0, rccl_groups=0, d2d_copies=0) if static_sigma else dict(reports[0], kernel_launches=n1)
+        later = dict(reports[0], kernel_launches=n1)     # (static sigma: k_scan skips the statistics -- the same launches)
         assert all(r == later for r in reports[1:]), reports
     finally:
         ctx.close()
@@ -161,7 +160,7 @@ def test_band_step_follows_a_changing_coast(oracles):
             for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
-        assert launches == [8, 7, 7, 7, 7, 7], launches     # k_prep in the first step only
+        assert launches == [6, 5, 5, 5, 5, 5], launches     # k_prep in the first step only
     finally:
         ctx.close()
 

@@ -72,7 +72,7 @@ band = timed(lambda tn: ctx.band_seabreeze_diag_dev(dt, 1440.0, tn, nx, nyb, nz,
 rep = ctx.last_step_report()
 print(f"band of {nx}x{nyb}x{nz}, halo {h}: plain call {plain:.1f} us, band step (one-rank communicator) {band:.1f} us, "
       f"band machinery {band - plain:.1f} us per step; a band step enqueues {rep} (an interior rank of a multi-rank run: "
-      f"4 RCCL sends/receives in one group + 1 all-gather instead of the copy)")
+      f"4 RCCL sends/receives in one group + 1 all-gather on top)")
 # opt-in: sigma's statistics formed once (sb_set_static_sigma): no moments pass, no all-gather, no merge after step 1
 ctx.set_static_sigma(True)
 band_s = timed(lambda tn: ctx.band_seabreeze_diag_dev(dt, 1440.0, tn, nx, nyb, nz, h, *args, stream))
