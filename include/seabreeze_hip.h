@@ -367,6 +367,13 @@ int sb_comm_finalize(sb_ctx *ctx);
 int sb_swap_bounds_f64_dev(sb_ctx *ctx, double *field, int nx, int ny, int halo, void *stream);
 int sb_swap_bounds_f32_dev(sb_ctx *ctx, float *field, int nx, int ny, int halo, void *stream);
 int sb_allgather_moments_dev(sb_ctx *ctx, const double *mine5, double *gathered, void *stream);
+/* The local part of sb_swap_bounds_*_dev on its own, for a host model that moves the north-south ghost rows with its
+   own message passing (ref: generic/halo_exchange_mod.f90:12-17, where swap_bounds stands for "various routines about
+   communications across processors"): the east-west ghost columns of every row -- ghost rows included -- become the
+   periodic wrap, and a band that touches a pole (south / north != 0) replicates its edge row into the ghost rows on
+   that side first.  No communicator is needed or used.                                                          */
+int sb_fill_ghosts_f64_dev(sb_ctx *ctx, double *field, int nx, int ny, int halo, int south, int north, void *stream);
+int sb_fill_ghosts_f32_dev(sb_ctx *ctx, float *field, int nx, int ny, int halo, int south, int north, void *stream);
 /* One seabreeze_diag step of a latitude band, device pointers, as sb_seabreeze_diag_*_dev with
    bnd = SB_BND_HALO -- plus the band's communication: the sigma moments are reduced over all
    bands and theta's ghost cells are filled (swap_bounds) inside the call, on the context's

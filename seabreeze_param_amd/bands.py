@@ -151,6 +151,8 @@ class BandRunner:
         self.z, self.sigma, self.mask = (self._halo_field(a) for a in (z, sigma, mask))
         for a in (self.z, self.sigma, self.mask):      # static fields: ghosts exchanged once
             self._fill_ghosts(a)
+        self.torch.cuda.synchronize()                  # (torch wrote them; the library reads them on streams of its own)
+        self.ctx.synchronize()
 
     def upload_step_inputs(self, p, u, v, theta, local3d=False):
         """p, u, v: the full (nz, ny, nx) fields, or with local3d=True only this band's rows
@@ -162,6 +164,7 @@ class BandRunner:
             band3 = lambda a: t.from_numpy(np.ascontiguousarray(a[:, self.r0:self.r1])).to(self.dev)
         out = dict(p=band3(p), u=band3(u), v=band3(v), theta=self._halo_field(theta))
         assert out["p"].shape == (self.nz, self.nyl, self.nx), out["p"].shape
+        t.cuda.synchronize()                           # (as above: torch wrote them, the library reads them)
         return out
 
     # -- one model step -------------------------------------------------------------------
@@ -177,15 +180,21 @@ class BandRunner:
                                              self.thc.data_ptr(), self.sb_con.data_ptr(), stream)
             return
         if self.world > 1:
+            # (torch's transport: torch and the library each bring a HIP runtime and streams of their own, and nothing
+            # orders the two -- every hand-over is a synchronisation on the side that wrote last.  The native path
+            # above has no such hand-over inside a step.)
             if not (self.static_sigma and self._stats_done):
                 self.ctx.sigma_moments_dev(self.dtype, self.nx, self.nyl, self.h, self.sigma.data_ptr(),
                                            self.mom.data_ptr(), stream)
                 if self.comm == "native":
                     self.ctx.allgather_moments_dev(self.mom.data_ptr(), self.gath.data_ptr(), stream)
                 else:
+                    self.ctx.synchronize()
                     self.dist.all_gather_into_tensor(self.gath, self.mom)
                 self._stats_done = True
             self._fill_ghosts(s["theta"])               # theta changes every step
+            if self.comm != "native":
+                t.cuda.synchronize()
         self.ctx.seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h, self.bnd,
                                     s["p"].data_ptr(), s["u"].data_ptr(), s["v"].data_ptr(),
                                     s["theta"].data_ptr(), self.mask.data_ptr(), self.z.data_ptr(),

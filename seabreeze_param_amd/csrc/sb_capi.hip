@@ -287,7 +287,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.partials = c->partials; lc.stats = c->stats;
     lc.gathered = c->gathered; lc.ngathered = c->ngathered; lc.ncu = c->ncu;
     lc.moments_out = (phases == 1) ? c->band_moments_out : nullptr;   // (a band step: k_scan publishes this band's moments)
-    lc.moments_event = (phases == 1) ? c->ev_mom : nullptr;
+    lc.moments_event = (phases == 1 && c->nranks > 1) ? c->ev_mom : nullptr;   // (one rank: nobody waits for them)
     lc.stats_ticket = (int *)c->ticket + 1;
     lc.phases = phases;
     lc.reuse_stats = reuse_stats<T>(c, job.sigma, g.nx, g.ny, g.h);
@@ -300,7 +300,11 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     int launched = 0;
     lc.launches = &launched;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
-    HIPCHK(c, sb_launch_diag<T>(job, Hk, lc));
+    {
+        const hipError_t le = sb_launch_diag<T>(job, Hk, lc);
+        if (le == hipErrorInvalidValue) return fail(c, SB_ERR_ARG, "no contrast kernel instance for this halo / tile shape");
+        if (le != hipSuccess) return hipfail(c, le, "sb_launch_diag");
+    }
     c->rep_launches += launched;
     if (!(phases & 2)) return SB_OK;          // the flag buffers swap when the call is complete
     c->segs_built = strip_folds;
@@ -1285,6 +1289,15 @@ int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream)
 }
 }  // namespace
 
+template <typename T>
+static int fill_ghosts_dev(sb_ctx *c, T *field, int nx, int ny, int halo, int south, int north, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!field || nx < 1 || ny < 1 || halo < 0) return fail(c, SB_ERR_ARG, "bad fill_ghosts arguments");
+    if (halo == 0) return SB_OK;
+    HIPCHK(c, sb_launch_fill_ghosts<T>(field, nx, ny, halo, south ? 1 : 0, north ? 1 : 0, stream ? (hipStream_t)stream : c->stream));
+    return SB_OK;
+}
+
 extern "C" {
 
 int sb_comm_get_unique_id(unsigned char id[128]) {
@@ -1350,6 +1363,13 @@ int sb_swap_bounds_f64_dev(sb_ctx *c, double *field, int nx, int ny, int halo, v
 }
 int sb_swap_bounds_f32_dev(sb_ctx *c, float *field, int nx, int ny, int halo, void *stream) {
     return swap_bounds_dev<float>(c, field, nx, ny, halo, stream);
+}
+
+int sb_fill_ghosts_f64_dev(sb_ctx *c, double *field, int nx, int ny, int halo, int south, int north, void *stream) {
+    return fill_ghosts_dev<double>(c, field, nx, ny, halo, south, north, stream);
+}
+int sb_fill_ghosts_f32_dev(sb_ctx *c, float *field, int nx, int ny, int halo, int south, int north, void *stream) {
+    return fill_ghosts_dev<float>(c, field, nx, ny, halo, south, north, stream);
 }
 
 }  // extern "C"

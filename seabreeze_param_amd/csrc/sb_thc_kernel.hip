@@ -242,6 +242,11 @@ __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, 
     __shared__ Moments s_wpart[FOLD ? NT / SB_WAVE : 1];
     __shared__ int s_scan[NT / SB_WAVE];
     __shared__ T s_sdr[2];                                       // band step: the sigmoid scalars the first wave derived
+    // (a tile shape that does not fit is a compile error here, not a launch that aborts on the device: an instance of
+    // 219,528 bytes once got as far as the GPU box)
+    static_assert(sizeof(sA) + sizeof(sL) + sizeof(sC) + sizeof(pA) + sizeof(pL) + sizeof(pC) + sizeof(s_land) + sizeof(s_word) +
+                          sizeof(s_cell) + sizeof(s_bits) + sizeof(s_wpart) + sizeof(s_scan) + sizeof(s_sdr) + 64 <= 160 * 1024,
+                  "k_thc3: the LDS of one workgroup");
 
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -784,8 +789,13 @@ static void launch_thc3(const DiagJob<T> &job, int nblocks, hipStream_t st) {
 template <typename T>
 hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st) {
     const int nblocks = ncu;                     // one persistent workgroup per CU
-    if (H <= 24) launch_thc3<T, THC_TX, THC_TY24, 24, 512>(job, nblocks, st);
-    else launch_thc3<T, THC_TX, THC_TY32, 32, 512>(job, nblocks, st);   // H == 32
+    // (the two instances that exist; anything else -- a halo the tables cannot hold, a tile grid other than the one
+    // sb_thc_tile_shape gave for this halo -- is refused here rather than launched)
+    int tx, ty;
+    sb_thc_tile_shape(H, &tx, &ty);
+    if ((H != 24 && H != 32) || job.thc_ty != ty || job.thc_txs != (tx == 32 ? 5 : 6) || job.strip) return hipErrorInvalidValue;
+    if (H == 24) launch_thc3<T, THC_TX, THC_TY24, 24, 512>(job, nblocks, st);
+    else launch_thc3<T, THC_TX, THC_TY32, 32, 512>(job, nblocks, st);
     return hipGetLastError();
 }
 template hipError_t sb_launch_thc<float>(const DiagJob<float> &, int, int, hipStream_t);

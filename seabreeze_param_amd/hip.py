@@ -232,6 +232,11 @@ class Context:
         return cdist
 
     # ------------------------------------------------------------------ device-pointer API
+    def sigmoid_dev(self, dtype, nx, ny, ary, sm, stream=None):
+        """sm = 1/(1+exp(-std*(ary-r))) on device arrays (raw addresses); enqueues without synchronising."""
+        fn = getattr(self.lib, f"sb_sigmoid_{_SFX[np.dtype(dtype)]}_dev")
+        self._chk(fn(self.h, C.c_int(nx), C.c_int(ny), _p(ary), _p(sm), C.c_void_p(stream) if stream else None), "sb_sigmoid_dev")
+
     def seabreeze_diag_dev(self, dtype, timestep, tn, nx, ny, nz, halo, bnd, p, u, v, theta, mask, z, sigma,
                            ws, wd, thc, sb_con, stream=None, tunables: Tunables | None = None):
         """All array arguments are raw device addresses (ints); enqueues without synchronising."""
@@ -284,6 +289,12 @@ class Context:
         fn = getattr(self.lib, f"sb_swap_bounds_{_SFX[np.dtype(dtype)]}_dev")
         self._chk(fn(self.h, _p(field), C.c_int(nx), C.c_int(ny), C.c_int(halo),
                      C.c_void_p(stream) if stream else None), "sb_swap_bounds_dev")
+
+    def fill_ghosts_dev(self, dtype, field, nx, ny, halo, south, north, stream=None):
+        """The local part of swap_bounds: E-W wrap of every row, pole replication where south / north is set."""
+        fn = getattr(self.lib, f"sb_fill_ghosts_{_SFX[np.dtype(dtype)]}_dev")
+        self._chk(fn(self.h, _p(field), C.c_int(nx), C.c_int(ny), C.c_int(halo), C.c_int(1 if south else 0),
+                     C.c_int(1 if north else 0), C.c_void_p(stream) if stream else None), "sb_fill_ghosts_dev")
 
     def band_seabreeze_diag_dev(self, dtype, timestep, tn, nx, ny, nz, halo, p, u, v, theta, mask, z, sigma,
                                 ws, wd, thc, sb_con, stream=None, tunables: Tunables | None = None):

@@ -50,6 +50,7 @@ def _worker(rank, world, port, nx, ny, nz, tmpdir, static_sigma=False):
             u, v = synth.wind_step(st, nz, tn)
             s = runner.upload_step_inputs(p, u, v, th)
             runner.step(7200.0, tn, s)
+            ctx.synchronize()
             torch.cuda.synchronize()
             orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *full, halo=0, bnd=1)
             for nm, mine, ref in zip(("ws", "wd", "thc", "sb_con"),

@@ -165,6 +165,73 @@ def test_band_step_follows_a_changing_coast(oracles):
         ctx.close()
 
 
+@pytest.mark.parametrize("prec", [8, 4])
+def test_fill_ghosts_of_an_interior_band(prec):
+    """The local ghost fill as an interior rank of a multi-rank run sees it (south = north = 0: the ghost rows came
+    over the wire and must be kept, only their east-west ghost columns are wrapped) and as the two pole ranks see it,
+    against the torch path of BandRunner (bands.fill_ew_ghosts / the pole rule of bands.exchange_ns).  Everything of
+    a multi-rank exchange but the RCCL wire itself, which this one-GPU box cannot carry."""
+    from seabreeze_param_amd import bands
+    dt = np.float64 if prec == 8 else np.float32
+    nx, nyl, h = 200, 40, 6
+    rng = np.random.default_rng(11)
+    ctx = hip.Context(0)
+    try:
+        for south, north in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            host = rng.standard_normal((nyl + 2 * h, nx + 2 * h)).astype(dt)     # ghost rows: "what the neighbours sent"
+            want = host.copy()
+            if south:
+                want[0:h] = want[h:h + 1]
+            if north:
+                want[nyl + h:] = want[nyl + h - 1:nyl + h]
+            bands.fill_ew_ghosts(want, nx, h)
+            dev = torch.from_numpy(host).cuda()
+            torch.cuda.synchronize()
+            ctx.fill_ghosts_dev(dt, dev.data_ptr(), nx, nyl, h, south, north)
+            ctx.synchronize()
+            assert np.array_equal(dev.cpu().numpy(), want), (south, north)
+    finally:
+        ctx.close()
+
+
+def test_static_sigma_does_not_outlive_other_statistics(oracles):
+    """sb_set_static_sigma keeps the sigmoid scalars of the first call -- but they share a scratch buffer with the
+    stand-alone sigmoid: diag, sb_sigmoid_*_dev on another field, diag again must form sigma's statistics anew
+    (ADVICE round 2).  Every diag matches the oracle, which recomputes them every call (ref: generic/...f90:457-481)."""
+    from seabreeze_param_amd import synth
+    nx, ny, nz = 256, 192, 3
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=5)
+    p = synth.pressure_3d(st, nz, dt)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ctx = hip.Context(0)
+    try:
+        ctx.set_static_sigma(True)
+        z, mk, pd, sg = dev(st.z), dev(cdist), dev(p), dev(st.sigma)
+        other = dev(st.z * 3.0 + 11.0)
+        sm = torch.empty_like(other)
+        state = [torch.zeros((ny, nx), dtype=torch.float64, device="cuda") for _ in range(4)]
+        ref = [np.zeros((ny, nx)) for _ in range(4)]
+        for tn in (1, 2, 3, 4):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            ud, vd, thd = dev(u), dev(v), dev(th)
+            torch.cuda.synchronize()
+            if tn == 3:                                  # another field's scalars land in the shared scratch
+                ctx.sigmoid_dev(dt, nx, ny, other.data_ptr(), sm.data_ptr())
+            ctx.seabreeze_diag_dev(dt, 7200.0, tn, nx, ny, nz, 0, hip.SB_BND_GLOBAL, pd.data_ptr(), ud.data_ptr(), vd.data_ptr(),
+                                   thd.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(), *[s.data_ptr() for s in state])
+            ctx.synchronize()
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *ref, halo=0, bnd=1)
+            for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
+                err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
+                assert err < 1e-7, f"step {tn} {nm}: {err}"
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("fold", [True, False], ids=["fold", "kprep"])
 def test_static_sigma_single_domain(oracles, fold):
     """sb_set_static_sigma on a single domain: the statistics of the first call stand while the same device

@@ -162,8 +162,9 @@ def test_dummy_model_band_mode_one_rank_communicator(tmp_path, oracles, prec):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert idf.exists() and idf.stat().st_size == 128
-    # one rank: k_stats + merge, ghost fill, k_scan, k_prep, k_wind, k_thc3; the all-gather degenerates to a copy
-    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 7 0 0 1" in r.stdout, r.stdout
+    # one rank, last step: the ghost fill; k_scan (which publishes the band's moments -- for one rank the gathered set),
+    # k_wind on the segment lists of the step before, the strip kernel, the update
+    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 5 0 0 0" in r.stdout, r.stdout
     raw = np.fromfile(fout, dtype=dt)
     n2 = nx * ny
     orc = oracles[prec]

@@ -215,6 +215,33 @@ def test_stored_plan_follows_the_planes(hipctx, oracles, flavour):
             _assert_close64(a, b, f"{flavour} call {tn} state {nm}")
 
 
+def test_alternating_grids_and_contrast_kernels_in_one_context(hipctx, oracles):
+    """Twenty calls that alternate between two grids and between the strip kernel (halo 16) and the tile kernel (halo 24)
+    inside ONE context: every switch re-sizes the block-flag buffers, whose zeroing once ran on the null stream --
+    unordered against the streams the kernels run on -- and now and then wiped flags k_scan had just raised (commit
+    38de1a5).  Every call matches the oracle; no band cell is left without its contrast."""
+    dt, orc = np.float64, oracles[8]
+    cases = []
+    for (nx, ny, nz), hint in (((96, 72, 2), 16), ((130, 75, 2), 24)):
+        st = synth.static_fields(nx, ny, dt)
+        coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+        cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=4)
+        cdist[np.abs(cdist) > 180.0] = 12000.0
+        cases.append(dict(st=st, cdist=cdist, p=synth.pressure_3d(st, nz, dt), nz=nz, hint=hint,
+                          so=_states(ny, nx, dt, 4), sh=_states(ny, nx, dt, 4)))
+    for call in range(20):
+        c = cases[call % 2]
+        tn = call // 2 + 1
+        th = synth.theta_step(c["st"], tn, dt)
+        u, v = synth.wind_step(c["st"], c["nz"], tn, dt)
+        hipctx.set_search_radius_hint(c["hint"])
+        orc.seabreeze_diag(7200.0, tn, c["p"], u, v, th, c["cdist"], c["st"].z, c["st"].sigma, *c["so"], halo=0, bnd=1)
+        hipctx.seabreeze_diag(7200.0, tn, c["p"], u, v, th, c["cdist"], c["st"].z, c["st"].sigma, *c["sh"], halo=0, bnd=hip.SB_BND_GLOBAL)
+        for a, b, nm in zip(c["sh"], c["so"], ("ws", "wd", "thc", "sb_con")):
+            _assert_close64(a, b, f"call {call} {nm}")
+    hipctx.set_search_radius_hint(16)
+
+
 @pytest.mark.parametrize("shape", [(96, 72, 3), (256, 192, 2)])
 def test_wrapper_flavour_fp32(hipctx, oracles, shape):
     nx, ny, nz = shape
