@@ -5,21 +5,23 @@
 // stream for a host-model call on a single domain, four or five otherwise:
 //
 //   k_scan   one pass over sigma and mask: per-workgroup shifted sums of sigma, the band and
-//            land-side bit planes, tile flags, and the fill value for every cell outside
-//            the coastal band                                                  [HBM stream]
-//   k_prep   (f2py flavour, band steps, very large tile counts, sb_set_fold(ctx, 0); otherwise k_thc3 does
-//            this work itself) 2 + SB_SEG_PARTS workgroups: the sums merged into the sigmoid scalars, the
-//            tile flags compacted into the list of active tiles (for k_thc3), the band plane into the
-//            lists of 64-cell segments that hold band cells (for k_wind)      [tiny]
+//            land-side bit planes (compared word by word with those of the call before: the strip
+//            kernel's stored plan stands while they do), block flags, and the fill value for every
+//            cell outside the coastal band                                    [HBM stream]
+//   k_prep   (f2py flavour, search radii beyond 16, the first step of a band run, sb_set_fold(ctx, 0);
+//            otherwise the strip kernel does this work itself) 2 + SB_SEG_PARTS workgroups: the sums
+//            merged into the sigmoid scalars, the tile flags compacted into the list of active tiles
+//            (for k_thc3), the band plane into the lists of 64-cell segments that hold band cells
+//            (for k_wind)                                                      [tiny]
 //   k_t0     f2py flavour only: the t0 plane is an output there               [HBM stream]
-//   k_thc3   (sb_thc_kernel.hip) per active 32 x TY tile: t0 and its summed-area tables in
-//            LDS, bisection for the window radius -> thc                      [VALU + LDS]
+//   k_strip  (sb_strip_kernel.hip; radii up to 16) t0 and its summed-area tables marched through a
+//            ring in LDS, strip by strip -> thc; k_thc3 (sb_thc_kernel.hip) per tile for radii
+//            up to 32                                                          [VALU + LDS]
 //   k_wind   per listed segment: level nearest target_plev in the p column of every band
 //            cell, wind speed / direction, thresholds, scaling, state update   [HBM gather]
 //
-// A band step of a multi-GPU run launches k_wind before its ghost rows arrive (it then leaves
-// this call's wind for k_thc3, which applies thresholds and update itself).  The overlap mode
-// (sb_set_overlap, a measured experiment, off by default) splits k_wind into k_walk || k_thc3 and k_final.
+// A band step of a multi-GPU run launches k_wind before its ghost rows arrive (instance <0>: the winds go
+// to scratch planes) and applies thresholds and update behind the contrast kernel (instance <2>).
 // Memory-bound integer/fp64 work: no MFMA anywhere.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"

@@ -23,13 +23,18 @@
 //     fp64 scan took two DPP moves and a half-rate v_add_f64,
 // (c) make the result independent of how the grid is cut into strips, blocks, bands or GPUs, bit for bit.
 //
-// Per block (one barrier):
+// Per block (one barrier, LDS only: the prefetched global loads stay in flight):
 //   S1  every wave: its row's inputs (prefetched three blocks ahead into registers) -> t0 -> fixed point ->
-//       prefix along longitude of {all, land-side, land-side count} -> ring row (not yet summed along latitude)
-//   --- barrier (LDS only: the prefetched global loads stay in flight) ---
-//   S2  waves 0-2: one table each, prefix along latitude of the 16 new rows (running column totals in registers)
-//       waves 3-10: band cells of the block staged two steps ago: bisection for the radius, contrast, result
+//       prefix along longitude of {all, land-side, land-side count} -> ring row (not yet summed along latitude);
+//       without a stored plan waves 8-15 also list the band cells of the block that is queried in this step
+//   --- barrier ---
+//   S2  waves 5-7: one table each, prefix along latitude of the 16 new rows (running column totals in registers)
+//       waves 0-7: 64 band cells each of the block staged two steps ago: window radius, contrast -> thc
 //       (the other waves go straight on to S1 of the next block)
+//
+// The plan -- shares, order of steps, cell lists with every window's radius, count and class -- is stored in device
+// memory and used again for as long as k_scan finds the band and land-side planes unchanged (see `cached` below).
+// DESIGN.md section 2.4 has the measurements behind the choices, and what hipcc does with loads kept in flight.
 #include "sb_thc_common.hpp"
 
 #define STRIP_H 16                // halo of the tables = largest radius answered from LDS

@@ -175,10 +175,16 @@ def test_meta_finds_inputs_and_writes_results(tmp_path, monthly):
 
 
 @pytest.mark.gpu
-def test_file_driver_end_to_end(tmp_path):
-    """run_seabreeze.main on two daily files: the result files hold what diag returns for the same arrays, with the
-    timestep counter and the carried state threaded from the first file into the second."""
+def test_file_driver_end_to_end(tmp_path, oracles):
+    """run_seabreeze.main on two daily files: the result files hold what the CPU ORACLE computes stepping the files'
+    arrays (wrapper flavour, fp32: coast from the land mask and every step's ice, coast distance, diag with the carried
+    state -- the sequence of ref python_wrapper/seabreezediag/__init__.py:222-245), and, bit for bit, what
+    seabreezediag.diag returns for the same arrays; the timestep counter and the state are threaded from the first
+    file into the second."""
     sbd, configdir, ncio = _surface()
+    orc = oracles[4]
+    so = None
+    otn = 1
     import run_seabreeze
     root = str(tmp_path)
     stamps = ["1987_01_01", "1987_01_02"]
@@ -195,6 +201,20 @@ def test_file_driver_end_to_end(tmp_path):
             got = np.array(f.variables["sb_con"][:])
             assert got.shape == (NT, NLAT, NLON)
             assert np.array_equal(got, sb.astype(np.float32), equal_nan=True)
+            # ... and the oracle, stepping the same arrays
+            f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+            if so is None:
+                so = [np.zeros((NLAT, NLON), np.float32) for _ in range(3)]
+            for k in range(NT):
+                coast = orc.get_edges(f32(st.landfrac), f32(d["ci"][k]))
+                cdist = orc.get_dist(coast, f32(st.landfrac), f32(st.lon), f32(st.lat))
+                oo = orc.diag(otn, f32(pres), f32(st.z), f32(st.sigma), f32(d["th"][k]), f32(d["v"][k]), f32(d["u"][k]), cdist, *so)
+                otn += 1
+                band = oo[0, :-1] < 1e19
+                near = np.abs(np.abs(so[2][:-1]) - 0.75) < 5e-3            # the 0.75 K knife edge of the trigger
+                ok = band & ~near
+                assert np.array_equal(got[k, :-1][~band] > 1e19, np.ones((~band).sum(), bool)), (stamp, k)
+                assert np.max(np.abs(got[k, :-1][ok] - oo[0, :-1][ok]), initial=0.0) < 5e-3, (stamp, k)
             first = datetime.strptime(stamp, "%Y_%m_%d")
             assert list(f.variables["time"][:]) == [int((first + timedelta(hours=6 * i) - datetime(1970, 1, 1)).total_seconds())
                                                      for i in range(NT)]

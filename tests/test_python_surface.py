@@ -202,6 +202,38 @@ def test_streamed_driver_250_steps_against_oracle(oracles):
     assert np.max(np.abs(ws[:-1] - oo[2, :-1])) < 1e-4 and np.max(np.abs(t0[:-1] - oo[1, :-1])) < 1e-3
 
 
+@pytest.mark.gpu
+def test_streamed_driver_1e4_steps_against_oracle(oracles):
+    """BASELINE configs[4] at its length: 10^4 timesteps through seabreezediag.diag in chunks of 100 (256x192x8, fp32,
+    the state threaded from call to call as the reference's test_run.py does, ref: python_wrapper/test_run.py:23-57)
+    against the CPU oracle's wrapper flavour stepping the same inputs.  The carried state of the last step and every
+    500th sb_con plane are compared; a drift or a lost hand-over between chunks would show."""
+    assert _built()
+    _, sbd = _import_surface()
+    chunk, nchunks, nlat, nlon, nlev = 100, 100, 192, 256, 8
+    st, pres, u, v, t, ci = _stream_case(chunk, nlat, nlon, nlev)
+    kw = dict(timestep=24.0, maxdist=180.0)
+    orc = oracles[4]
+    coast = orc.get_edges(st.landfrac, ci[0])
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat)
+    so = [np.zeros((nlat, nlon), np.float32) for _ in range(3)]
+    tt, ws, wd, thc = 1, None, None, None
+    bad = 0
+    for c in range(nchunks):
+        state = {} if ws is None else dict(ws=ws, wd=wd, thc=thc)
+        tt, sb, thc, ws, wd = sbd.diag(tt, st.landfrac, st.z, st.sigma, st.lon, st.lat, pres, u, v, t, ci, **state, **kw)
+        for k in range(chunk):
+            oo = orc.diag(c * chunk + k + 1, pres, st.z, st.sigma, t[k], v[k], u[k], cdist, *so, **kw)
+            if (c * chunk + k) % 500 == 499:
+                near = np.abs(np.abs(so[2][:-1]) - 0.75) < 5e-3
+                band = oo[0, :-1] < 1e19
+                ok = band & ~near
+                bad += int((np.abs(sb[k, :-1][ok] - oo[0, :-1][ok]) > 5e-3).sum())
+    assert tt == 1 + chunk * nchunks and bad == 0
+    # (the third value the driver returns is the t0 plane of the last step, as in the reference: ref __init__.py:245)
+    assert np.max(np.abs(ws[:-1] - oo[2, :-1])) < 1e-4 and np.max(np.abs(np.asarray(thc)[:-1] - oo[1, :-1])) < 1e-3
+
+
 def test_extension_reports_errors_instead_of_stopping_the_interpreter():
     """Without a GPU every routine of the f2py surface fails in sb_create: the extension must leave a status and a
     message (and the Python layer raise), not end the process (the first version ran `error stop`)."""
