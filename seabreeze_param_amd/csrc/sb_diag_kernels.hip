@@ -211,7 +211,7 @@ __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__re
         {
             const unsigned seg = s0 + (unsigned)(lane >> 1) * nwaves;
             const uint64_t *plane = (lane & 1) ? job.clsbits : job.bandbits;
-            t.old = plane[(lane < 2 * SPT && seg < nseg) ? seg : 0u];
+            t.old = plane[(lane < 2 * SPT && seg < nseg) ? seg : 0u];     // (measured: 0.2-0.6 us of k_scan's 24, A/B on one box)
         }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
