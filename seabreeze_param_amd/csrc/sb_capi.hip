@@ -294,7 +294,6 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     lc.no_fold = c->no_fold != 0;
     const bool strip_folds = strip && job.t0_fly && !c->no_fold;
     lc.segs_stand = strip_folds && c->gathered && c->plan_use && c->segs_built && !c->no_plan_cache;
-    job.no_prefetch = 1;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
     job.gath = nullptr; job.ngath = 0;
     int launched = 0;

@@ -295,7 +295,6 @@ struct DiagJob {
     // and the active tiles picked by every workgroup for itself, the segment lists compacted in its last workgroups
     const Moments *gath;            // band step: the moments gathered from every rank (ngath of them), merged by the first wave
     int ngath;                      //   of every k_thc3 workgroup in k_merge_moments' tree; 0: the scalars in stats stand
-    int no_prefetch;                // k_thc3 without its register prefetch (it runs beside k_wind: overlap mode)
     int fold;
     const Moments *fold_partials;   // k_scan's per-workgroup moments (fold_nparts of them; 0: the scalars in stats stand)
     int fold_nparts;

@@ -390,9 +390,8 @@ template hipError_t sb_launch_theta_to_t0<double>(double *, const double *, cons
 // k_prep: the small jobs between k_scan and the kernels that consume its flags, one role per
 // workgroup (2 + SB_SEG_PARTS workgroups), so that neither the 256 persistent workgroups of k_thc3 nor
 // the waves of k_wind repeat them:
-//   block 0               k_scan's per-workgroup shifted sums added up in index order, in the fixed tree of
-//                         k_moments_final, into the sigmoid scalars (or published as this band's
-//                         moments for the multi-GPU gather)
+//   block 0               k_scan's per-workgroup shifted sums added up in index order (a fixed tree) into the
+//                         sigmoid scalars
 //   block 1               tile flags -> row-major list of active tiles: tile_list[0] = count, then the tiles, then
 //                         tile_pad entries of -1
 //   blocks 2 .. 2+PARTS-1 band plane -> the 64-cell segments that hold band cells, each part a

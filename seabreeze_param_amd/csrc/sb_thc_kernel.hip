@@ -34,10 +34,6 @@
 #define THC_QI 0                  // list entries a thread takes through the search rounds together; 0: by workgroup size
 #endif
 #define THC_TX 32
-#define THC_TY 48
-#define THC_TYL 64                // taller tiles, by sb_set_tile_rows only
-#define THC_TYS 32                // small grids (a band of a multi-GPU run, N512): half-height tiles, so that more
-                                  // of the one-workgroup-per-CU grid has a tile and each tile is shorter
 #define THC_TY24 32               // tile rows with a halo of 24 (81 x 81 table entries)
 #define THC_TY32 16               // tile rows with a halo of 32: 81 x 97 table entries are what 160 KB of LDS hold
 
@@ -206,8 +202,11 @@ __device__ __forceinline__ int thc_fold_pick(const uint64_t *s_bits, int nwords,
 //     workgroup) while its first tile's loads are in flight; workgroup 0 publishes the scalars,
 //   * and the last SB_SEG_PARTS workgroups -- the ones the dealing gives one tile fewer whenever it is uneven --
 //     compact one sub-list each of the segments that hold band cells for k_wind, after their tiles.
-// PFX false (job.no_prefetch): no register prefetch of the next tile -- 160 instead of 228 registers per lane, which
-// leaves room on every SIMD for k_wind's waves when the two kernels run side by side (sb_launch_diag, overlap mode).
+// PFX false: no register prefetch of the next tile.
+// Since round 3 this kernel serves halos of 24 and 32 cells only (the strip kernel has the rest) and the library
+// instantiates it with FOLD = false, PFX = false (sb_launch_thc): k_prep makes the tile list and the scalars; with two
+// chunks per staged row a prefetched tile would not fit the registers anyway.  The FOLD and PFX paths stay in the
+// source as what was measured in round 2 (DESIGN.md, round 2 in the history).
 template <typename T, int TX, int TY, int H, int NT, bool FLY, bool WF, bool FOLD = false, bool PFX = true>     // WF: k_wind applies the update (job.wind_final)
 __global__ __launch_bounds__(NT) void k_thc3(const int *__restrict__ tile_list, const T *__restrict__ stats, int G, DiagJob<T> job) {
     constexpr int NWV = NT / SB_WAVE;
