@@ -233,7 +233,10 @@ __device__ __forceinline__ bool strip_is_mark(float v) { return __float_as_uint(
 // FLY: t0 from theta, z, sigma while staging.  The contrast goes to thc; thresholds and state update are k_wind's (a
 // cell's winds and state loaded here, next to the prefetched blocks of the march, would drain them at every step).
 template <typename T, bool FLY>
-__global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
+__global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_gen, const Moments *fold_partials, int G, StripJob<T> job) {
+    // (the three pointers the first loads of the kernel hang on come as leading arguments: with
+    // -amdgpu-kernarg-preload-count=7 they are in scalar registers when the wave starts, and the plan header, the
+    // change counter and k_scan's partial sums are requested without waiting for a load of the argument block)
     constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
     constexpr int RM = STRIP_RING - 1;
     static_assert(NWV == C && SW == 32, "one staged row per wave, 32 owned columns");
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     double shift_c = 0.0;
     const bool fold_stats = job.fold && job.fold_nparts > 0;
     if (fold_stats) {
-        if (tid < job.fold_nparts) pm = job.fold_partials[tid];
+        if (tid < job.fold_nparts) pm = fold_partials[tid];
         shift_c = (double)job.sigma[(size_t)g.h * g.nxh + g.h];
     } else if (FLY && job.ngath > 0) {
         // band step: the first wave merges the moments gathered from all ranks in rank order (one tree on every
@@ -295,11 +298,11 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(int G, StripJob<T> job) {
     // leaves the number of the last call that saw a difference.  A plan stored by that call or a later one is used as
     // it is: no flags are read, nothing is planned, no list is built.
     typedef const __attribute__((address_space(4))) int *cintp;
-    char *const plan_wg = job.plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
+    char *const plan_wg = plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
     unsigned *const plan_lists = (unsigned *)(plan_wg + SB_PLAN_LIST_OFF);
     const int plan_stored = ((cintp)plan_wg)[0], plan_nst = ((cintp)plan_wg)[1];
     const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
-    const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)job.plan_gen <= plan_stored;      // uniform
+    const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)plan_gen <= plan_stored;      // uniform
     auto load_plane = [&]() {
         u64 mine = 0;
         for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
@@ -971,8 +974,8 @@ hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st) {
     const dim3 gr(ncu), bl(STRIP_NT);                   // one persistent workgroup per CU
     const StripJob<T> sj = strip_job<T>(job);
     if (!job.wind_final) return hipErrorInvalidValue;   // (the update is k_wind's: sb_launch_diag sees to it)
-    if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true>), gr, bl, 0, st, ncu, sj);
-    else hipLaunchKernelGGL((k_strip<T, false>), gr, bl, 0, st, ncu, sj);
+    if (job.t0_fly) hipLaunchKernelGGL((k_strip<T, true>), gr, bl, 0, st, sj.plan, sj.plan_gen, sj.fold_partials, ncu, sj);
+    else hipLaunchKernelGGL((k_strip<T, false>), gr, bl, 0, st, sj.plan, sj.plan_gen, sj.fold_partials, ncu, sj);
     return hipGetLastError();
 }
 template hipError_t sb_launch_strip<float>(const DiagJob<float> &, int, hipStream_t);
