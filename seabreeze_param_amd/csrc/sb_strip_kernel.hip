@@ -300,7 +300,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
     typedef const __attribute__((address_space(4))) int *cintp;
     char *const plan_wg = plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
     unsigned *const plan_lists = (unsigned *)(plan_wg + SB_PLAN_LIST_OFF);
-    const int plan_stored = ((cintp)plan_wg)[0], plan_nst = ((cintp)plan_wg)[1];
+    const int plan_stored = ((cintp)plan_wg)[0], plan_nst = min(((cintp)plan_wg)[1], STRIP_SCHED);
     const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
     const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)plan_gen <= plan_stored;      // uniform
     auto load_plane = [&]() {
