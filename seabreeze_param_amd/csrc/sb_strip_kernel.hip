@@ -464,9 +464,14 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         }
         // (padded to a multiple of three with steps that do nothing: the march has no early exit -- with one, the
         // compiler's count of the loads in flight collapses and it drains the queue every third step)
+        // (The padding steps' dummy loads go where the last real step's went -- same strip, same block: no column
+        // arithmetic, lines that are in the cache.  A padding step cost 0.45 us, and the longest-lived workgroups of
+        // the headline grid have two.)
         n_out = min(n_out, STRIP_SCHED - 2);
         const int n_pad = (n_out + STRIP_DEPTH - 1) / STRIP_DEPTH * STRIP_DEPTH;
-        if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, 0u);
+        wave_sync();
+        const unsigned last_sj = s_ent[n_out - 1].y;         // (n_out >= STRIP_DEPTH + 1 here)
+        if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, last_sj);
         if (lane == 0) s_misc[0] = n_pad;
     };
     if (!cached) {
