@@ -869,9 +869,11 @@ int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const
         return fail(c, SB_ERR_ARG, "get_dist: window too large for the LDS tile");
     // phi = d2r*lat, folded lon in radians (ref: sobel.f90:130,165-174), host side: multiplies only
     const T pi = T(3.1415926), d2r = pi / T(180.0);
-    std::vector<T> hv((size_t)nx + ny);
+    std::vector<T> hv((size_t)3 * nx + ny);
     for (int i = 0; i < ny; ++i) hv[i] = d2r * lat[i];
     for (int j = 0; j < nx; ++j) hv[ny + j] = (lon[j] > T(180)) ? d2r * (lon[j] - T(360.)) : d2r * lon[j];
+    // half-angle tables of the folded longitudes (k_dist_bits, fp64: sin((l1 - l2) / 2) by the difference formula)
+    for (int j = 0; j < nx; ++j) { hv[ny + nx + j] = std::sin(hv[ny + j] / T(2)); hv[ny + 2 * (size_t)nx + j] = std::cos(hv[ny + j] / T(2)); }
     int rc = ensure(c, c->vecs, hv.size() * sizeof(T));
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -896,7 +898,8 @@ int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const
         latmono = ((double)lat[i + 1] - (double)lat[i]) * ((double)lat[i + 2] - (double)lat[i + 1]) > 0.0;
     for (int i = 0; i < ny && latmono; ++i) latmono = std::fabs((double)lat[i]) <= 90.0;
     const int nearest = (mono && latmono && turn < 360.0 + 1.0e-3 && (double)k * maxstep < 170.0) ? 1 : 0;
-    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, cdist, nx, ny, k, maxdist, (uint64_t *)c->coastbits.p, nearest, st));
+    HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, dlam + nx, dlam + 2 * (size_t)nx, cdist, nx, ny, k, maxdist,
+                                (uint64_t *)c->coastbits.p, nearest, st));
     // a distance field made here bounds the search radius of the following diag calls
     c->radius_hint = k + 1;
     return SB_OK;

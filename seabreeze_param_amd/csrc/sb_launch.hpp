@@ -67,7 +67,9 @@ template <typename T>
 hipError_t sb_launch_edges(const T *lsm, const T *ci, T *coast, int nx, int ny, int rule, int bnd, hipStream_t st);
 // phi: d2r*lat (ny), lamf: folded d2r*lon (nx), both device pointers
 template <typename T>
-hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf, T *cdist, int nx, int ny,
+hipError_t sb_launch_dist(const T *coast, const T *mask, const T *phi, const T *lamf,
+                          const T *shl, const T *chl,         // sin, cos of half the folded longitudes (k_dist_bits, fp64)
+                          T *cdist, int nx, int ny,
                           int k, T maxdist, uint64_t *bits,   // bits: ny*ceil(nx/64) words of workspace, or nullptr
                           int nearest,                        // 1: nearest hit per side of a source row only (see k_dist_bits)
                           hipStream_t st);
