@@ -175,32 +175,6 @@ __device__ __forceinline__ u64 sb_uniform64(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
-// the position of rank r among the set bits of the plane (bit b of word k = position 64 k + b), or -1; popcounts, a
-// wave scan per 64 words and ballots; wave-uniform, every wave computes the same
-__device__ __forceinline__ int strip_pick(const u64 *s_bits, int nwords, int r, int lane) {
-    int pos = -1, run = 0;
-    for (int k0 = 0; k0 < nwords; k0 += SB_WAVE) {
-        const u64 w = (k0 + lane < nwords) ? s_bits[k0 + lane] : 0ull;
-        const int pc = __popcll(w);
-        const int incl = sb_wave_scan_add(pc);
-        const int before = run + incl - pc;
-        run += __builtin_amdgcn_readlane(incl, SB_WAVE - 1);
-        const u64 hit = __builtin_amdgcn_ballot_w64(before <= r && r < before + pc);
-        if (hit) {                                               // wave-uniform; one lane of one chunk
-            const int src = __ffsll((unsigned long long)hit) - 1;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, src);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), src);
-            const u64 word = ((u64)hi << 32) | lo;
-            const int n = r - __builtin_amdgcn_readlane(before, src);
-            const bool me = ((word >> lane) & 1ull) && __popcll(word & ((1ull << lane) - 1ull)) == n;
-            const u64 sel = __builtin_amdgcn_ballot_w64(me);
-            pos = (k0 + src) * 64 + __ffsll((unsigned long long)sel) - 1;
-            break;
-        }
-    }
-    return pos;
-}
-
 // what a lane holds of one staged row between the issue of its loads and S1
 template <typename T, bool FLY>
 struct StripRegs {
@@ -555,9 +529,6 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         bool rowok = true;
         if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
-#if defined(STRIP_EXP) && (STRIP_EXP & 1)
-        Yr = (int)((blockIdx.x * 16 + wv) % (unsigned)g.nyh);   // experiment: a workgroup re-reads its own 16 rows (cache hits)
-#endif
         // (a scalar base -- field pointer plus the row's offset -- and the lane's 32-bit column offset: two scalar
         // registers per field where a buffer descriptor takes four)
         const size_t rowb = (size_t)((unsigned)Yr * (unsigned)g.nxh) * sizeof(T), wordb = (size_t)((unsigned)Yr * (unsigned)g.nw) * 8u;
@@ -867,16 +838,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
                 if (lister) bwd = band_issue(strip, jp - qoff);
                 if (tid == STRIP_NT - 1) s_misc[1 + (buf == 2 ? 0 : buf + 1)] = 0;   // the next step's list starts empty
                 if (!drain) stage(R, ent, jp);
-#if !(defined(STRIP_EXP) && (STRIP_EXP & 8))
                 if (lister) list_cells(strip, jp - qoff, bwd, buf);
-#endif
             }
             issue(R, J);                                          // (the one place of this copy of the step that loads)
             if (!idle) {
                 lds_barrier();
-#if !(defined(STRIP_EXP) && (STRIP_EXP & 4))
                 if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf, (ent >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
-#endif
                 if (!drain && wv >= 5 && wv < 8) vertical(jp);
             }
             // (Under the uniform condition, although every other load of the march is unconditional: with this load on
