@@ -315,7 +315,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     if ((rc = ensure(c, c->jobcopy, sizeof(DiagJob<double>)))) return rc;
     job.self = (DiagJob<T> *)c->jobcopy.p;
     job.plan = nullptr; job.plan_gen = nullptr; job.call_id = 0; job.plan_use = 0; job.seg_trust = 0;
-    job.moments_out = nullptr; job.stats_ticket = nullptr;
+    job.moments_out = nullptr; job.stats_ticket = nullptr; job.strip_update = 0;
     if (strip) {
         const size_t need = 64 + (size_t)c->ncu * SB_PLAN_STRIDE;
         if (c->plan.cap < need) {

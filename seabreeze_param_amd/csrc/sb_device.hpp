@@ -281,6 +281,7 @@ struct DiagJob {
     int plan_use;                   // 1: a plan stored by a call no older than *plan_gen may be used
     Moments *moments_out;           // band step: k_scan's last workgroup merges the partials and leaves this band's moments
     int *stats_ticket;              //   here (for the all-gather); a device word that is zero between launches
+    int strip_update;               // band step on the strip kernel: it applies thresholds and state update behind its march
     int seg_trust;                  // 1: k_wind's segment lists are those the strip kernel of the call before compacted;
                                     //    they stand unless k_scan found the planes changed in this call (*plan_gen == call_id)
     int *tile_nnmax;                // per contrast tile: 0 = no band cell; k_scan raises 1, k_thc3 leaves the largest radius
@@ -316,6 +317,7 @@ struct StripJob {
     int *flags;                     // strip-major block flags (DiagJob::tile_nnmax)
     int ntx, nty;                   // strips, blocks per strip
     int fold, fold_nparts, ngath, seg_cap;
+    int update;                     // band step: thresholds and state update of this workgroup's band cells behind the march
     const T *stats;
     T *stats_out;
     const Moments *fold_partials, *gath;

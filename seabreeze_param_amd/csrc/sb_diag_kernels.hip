@@ -21,7 +21,7 @@
 //            cell, wind speed / direction, thresholds, scaling, state update   [HBM gather]
 //
 // A band step of a multi-GPU run launches k_wind before its ghost rows arrive (instance <0>: the winds go
-// to scratch planes) and applies thresholds and update behind the contrast kernel (instance <2>).
+// to scratch planes); the contrast kernel applies thresholds and update behind its march.
 // Memory-bound integer/fp64 work: no MFMA anywhere.
 #include "sb_device.hpp"
 #include "sb_launch.hpp"
@@ -545,9 +545,8 @@ __device__ __forceinline__ T sb_ld(const T *p) {
     else return *p;
 }
 
-// MODE 0: the winds go to scratch planes (a band step, ahead of the contrast kernel); 1: ... and the update is applied
-// (single domain: the contrast kernel ran first); 2: no walk -- the winds of an earlier MODE 0 launch and the contrast
-// the strip kernel has left in thc since are read back and the update applied (a band step's last, small kernel)
+// MODE 0: the winds go to scratch planes (a band step, ahead of the contrast kernel, which applies the update);
+// 1: the update is applied here (single domain: the contrast kernel ran first)
 template <typename T, int UN, int MODE>
 __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T> job) {
     constexpr bool FINAL = MODE != 0;
@@ -588,10 +587,6 @@ __global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T>
         T n_thc = T(0), ws_old = T(0), wd_old = T(0);
         if constexpr (FINAL) { n_thc = job.thc[o]; ws_old = job.ws[o]; wd_old = job.wd[o]; }
         int lev = lev1;
-        if constexpr (MODE == 2) {
-            sb_trigger_update<T, false>(job, o, n_thc, SbCellState<T>{job.nws[o], job.nwd[o], ws_old, wd_old});
-            return;
-        }
         if (job.flavour == SB_FLAVOUR_GENERIC && job.level_rule == 0) {
             // whole batches of UN levels in flight; the last batch is padded by re-reading level
             // nz-1 (never a new minimum: the comparison is strict), so no serial tail of single
@@ -712,13 +707,6 @@ static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
     const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
     if (job.wind_final) hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 1>), wg, wb, 0, st, job);
     else hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 0>), wg, wb, 0, st, job);
-}
-
-// the update of a band step on the strip kernel: thc holds this call's contrast, the scratch planes its winds
-template <typename T>
-static void launch_update(const DiagJob<T> &job, int ncu, hipStream_t st) {
-    const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
-    hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 2>), wg, wb, 0, st, job);
 }
 
 // event pair k of a profiled call brackets kernel k (SB_PROF_*); pairs of kernels a call does not launch stay unrecorded
@@ -865,10 +853,12 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
             SB_EV_END(SB_PROF_T0);
             ++nl;
         }
-        // (the strip kernel leaves the contrast in thc whatever the order: a loop that loads a cell's winds and state
-        // next to the prefetched blocks of the march drains them at every step; the update is a kernel of its own)
+        // (the strip kernel leaves the contrast in thc whatever the order -- a loop that loads a cell's winds and state
+        // next to the prefetched blocks of the march drains them at every step -- and applies thresholds and state
+        // update behind its march, cell list by cell list)
         if (job.strip) {
             pj.wind_final = 1;
+            pj.strip_update = 1;
             // ... and compacts the segment lists: this call's update kernel reads them, and the next call's k_wind
             // if the planes stand (no k_prep then)
             if (job.t0_fly && !lc.no_fold) { pj.fold = 1; pj.fold_partials = nullptr; pj.fold_nparts = 0; if (!pj.stats_out) pj.stats_out = (T *)lc.stats; }
@@ -877,7 +867,6 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
         if ((e = launch_contrast<T>(pj, H, lc.ncu, st)) != hipSuccess) return e;
         SB_EV_END(SB_PROF_THC);
         ++nl;
-        if (job.strip) { launch_update<T>(job, lc.ncu, st); ++nl; }
     }
     if (lc.launches) *lc.launches += nl;
     return hipGetLastError();

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
     __shared__ int s_scan[NWV];
     __shared__ int s_misc[12];                         // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked,
                                                        // [5], [6] the share (ranks of active blocks), [7] totals of the plane,
-                                                       // [8] the plan of this call is stored (incl. its cell lists)
+                                                       // [8] the plan of this call is stored (incl. its cell lists),
+                                                       // [9] query steps of the plan (a band step's update)
     __shared__ T s_sdr[2];
     static_assert(sizeof(u64) * (2 * STRIP_RING * P + STRIP_RING + STRIP_MAXW) + 2 * STRIP_RING * P + 8 * STRIP_SCHED +
                           6 * SW * C + sizeof(Moments) * NWV + 4 * NWV + 48 + 16 <= 160 * 1024,
@@ -895,6 +896,70 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         }
     }
     SB_T(6);                                             // marked cells done
+    if (job.update) {
+        // ---- a band step: k_wind ran ahead of the ghost rows and left this call's winds in scratch planes; thresholds,
+        // scaling and state update (ref :235-266) of every band cell this workgroup queried, now that thc holds its
+        // contrast.  Behind the march, not inside it: a cell's winds and state loaded in a step would drain the blocks the
+        // march keeps in flight.  The cells come from the plan's lists (stored, or written by this very launch); four
+        // list rows per wave in flight.  thc is read past the L1 (other waves of this workgroup wrote it). ----
+        __syncthreads();
+        const DiagJob<T> &cj = *job.cold;
+        auto apply = [&](unsigned o) __attribute__((always_inline)) {
+            const T n_thc = __hip_atomic_load(&job.thc[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sb_trigger_update<T, false>(cj, (size_t)o, n_thc, sb_trigger_load<T>(cj, (size_t)o));
+        };
+        if (cached || store_lists) {
+            int *s_qblk = (int *)&s_cell[0][0];          // strip << 16 | block of every query step's list
+            if (tid == 0) s_misc[9] = 0;
+            __syncthreads();
+            const int nstp = s_misc[0];
+            for (int i = tid; i < nstp; i += STRIP_NT) {
+                const uint2 v = s_ent[i];
+                const bool dr = (v.x & SCH_DRAIN) != 0u;
+                if (!(v.x & SCH_IDLE) && (v.x & (dr ? SCH_Q1 : SCH_Q2)) != 0u) {
+                    const int qi = (int)((v.x >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
+                    s_qblk[qi] = (int)((v.y & 0xffff0000u) | ((v.y & 0xffffu) - (dr ? 1u : 2u)));
+                    atomicMax(&s_misc[9], qi + 1);
+                }
+            }
+            __syncthreads();
+            const int nrows = s_misc[9] * (C / 2);        // eight rows of 64 entries per list
+            for (int r0 = wv; r0 < nrows; r0 += 4 * NWV) {
+                unsigned code[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = r0 + k * NWV;
+                    code[k] = ~0u;
+                    if (r < nrows) code[k] = __hip_atomic_load(&plan_lists[(unsigned)(r >> 3) * (unsigned)(SW * C) + (unsigned)((r & 7) * SB_WAVE + lane)],
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (code[k] == ~0u) continue;
+                    const int blk = s_qblk[(r0 + k * NWV) >> 3];
+                    const int x = (blk >> 16) * SW + (int)(code[k] & 31u), y = ((blk & 0xffff) - 1) * C + (int)((code[k] >> 5) & 15u);
+                    apply((unsigned)y * (unsigned)g.nx + (unsigned)x);
+                }
+            }
+        } else {
+            // (no lists: a share of several rounds, or of more query steps than a plan holds -- block by block)
+            if (wv == 0) make_prefix(false);
+            __syncthreads();
+            tot_packed = s_misc[7];
+            for (int r = r_begin; r < r_end; ++r) {
+                int n;
+                const int kw = find_word(r, false, n);
+                if (kw < 0) break;
+                const int pos = kw * 64 + nth_bit(sb_uniform64(s_bits[kw]), n);
+                const int strip = pos / npad, jp = pos - strip * npad;
+                if (tid < SW * C) {
+                    const int x = strip * SW + (tid & (SW - 1)), y = (jp - 1) * C + (tid >> 5);
+                    if (x < g.nx && y >= 0 && y < g.rows && sb_bit(job.bandbits, g.nw, x + g.h, y + g.h))
+                        apply((unsigned)y * (unsigned)g.nx + (unsigned)x);
+                }
+            }
+        }
+    }
     if (job.fold) {
         // ---- k_wind's segment lists (k_prep's work on single-domain host-model calls): sub-list `part` holds the
         // segments with band cells of its contiguous range of the band plane, in ascending order ----
@@ -937,6 +1002,7 @@ static StripJob<T> strip_job(const DiagJob<T> &job) {
     s.seg_list = job.seg_list; s.seg_count = job.seg_count;
     s.cold = job.self;
     s.plan = job.plan; s.plan_gen = job.plan_gen; s.call_id = job.call_id; s.plan_use = job.plan_use;
+    s.update = job.strip_update;
     s.stamps = job.stamps;
     return s;
 }

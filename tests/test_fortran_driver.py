@@ -163,8 +163,8 @@ def test_dummy_model_band_mode_one_rank_communicator(tmp_path, oracles, prec):
     assert r.returncode == 0, r.stdout + r.stderr
     assert idf.exists() and idf.stat().st_size == 128
     # one rank, last step: the ghost fill; k_scan (which publishes the band's moments -- for one rank the gathered set),
-    # k_wind on the segment lists of the step before, the strip kernel, the update
-    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 5 0 0 0" in r.stdout, r.stdout
+    # k_wind on the segment lists of the step before, the strip kernel (contrast, then the update behind its march)
+    assert "band step enqueued (launches, RCCL ops, RCCL groups, copies): 4 0 0 0" in r.stdout, r.stdout
     raw = np.fromfile(fout, dtype=dt)
     n2 = nx * ny
     orc = oracles[prec]
