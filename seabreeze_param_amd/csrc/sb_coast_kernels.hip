@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_dist_bits(const uint64_t *__restrict__ 
     const T lamt = lamf[xx];
     const T cost = s_cost;
     // fp64: sin((l1 - l2) / 2) = sin(l1/2) cos(l2/2) - cos(l1/2) sin(l2/2) from per-column tables (the host forms
-    // them with the folded longitudes): two loads and an fma per hit where the library sine took some eighty
+    // them with the folded longitudes): two loads, two products and a difference per hit where the library sine took some eighty
     // instructions.  The difference of products carries an absolute error of 1e-16, i.e. <= 4e-13 relative in the
     // distance at the finest spacing in use (0.07 degrees); the tests hold 1e-12.  fp32 keeps the sine: there the same
     // identity would cost four digits.
@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256) void k_dist_bits(const uint64_t *__restrict__ 
             int xs = start + b;
             if (xs >= nx) xs -= nx;
             T sl;
-            if constexpr (sizeof(T) == 8) sl = __builtin_fma(shl[xs], cht, -(chl[xs] * sht));
+            // (two rounded products, no fma: for the target's own column they are the same product and the difference
+            // is exactly zero -- a coast cell's own distance stays exactly 0.5 km, SURVEY.md section 4's anchor)
+            if constexpr (sizeof(T) == 8) sl = shl[xs] * cht - chl[xs] * sht;
             else {
                 const T dlam = lamf[xs] - lamt;                  // l1 - l2
                 sl = sin(dlam / T(2));
