@@ -99,6 +99,12 @@ int  sb_set_plan_cache(sb_ctx *ctx, int on);
    (0, the default), or k_scan | join | contrast kernel, k_wind -- the three kernels of a single-domain call, one
    launch less, but less work to cover the communication with (1).  A measurement knob: results never depend on it.  */
 int  sb_set_band_order(sb_ctx *ctx, int contrast_first);
+/* The kernels that run one persistent workgroup per compute unit (k_scan, the contrast kernel; k_wind four per unit)
+   take n workgroups instead (1 .. the device's compute units; 0: back to the default).  A test knob -- with a few
+   workgroups a small grid exercises what only grids far beyond the BASELINE sizes reach otherwise: shares of the
+   strip kernel's march that span several rounds and hold more query steps than a stored plan does.  Results never
+   depend on it.                                                                                                  */
+int  sb_set_workgroups(sb_ctx *ctx, int n);
 /* Opt-in, off by default: the caller states that sigma (the sub-grid orography deviation, an ancillary that a
    host model reads once; ref: generic/sea_breeze_diag.f90:159-166 recomputes its mean and deviation every
    call) does not change between calls.  The first complete diag / band step after the switch forms the

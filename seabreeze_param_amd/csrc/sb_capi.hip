@@ -122,7 +122,8 @@ struct sb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int radius_hint = 16;
-    int ncu = 256;              // compute units of the device
+    int ncu = 256;              // persistent workgroups of the one-per-CU kernels: the device's compute units (sb_set_workgroups)
+    int ncu_dev = 256;          // compute units of the device
     // opt-in: sigma does not change between calls (sb_set_static_sigma): its statistics are kept from the first
     // complete call on the same array and k_scan stops reading it
     int static_sigma = 0;
@@ -1060,7 +1061,7 @@ int sb_create(sb_ctx **out, int device) {
                     std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     sb_ctx *c = new sb_ctx();
     c->device = device;
-    c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->ncu = c->ncu_dev = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return hipfail(nullptr, e, "hipStreamCreate");
@@ -1578,6 +1579,15 @@ int sb_allgather_moments_dev(sb_ctx *c, const double *mine5, double *gathered, v
 int sb_set_fold(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     c->no_fold = on ? 0 : 1;
+    return SB_OK;
+}
+
+int sb_set_workgroups(sb_ctx *c, int n) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (n < 0 || n > c->ncu_dev) return fail(c, SB_ERR_ARG, "sb_set_workgroups: 0 (the default) or 1 .. the device's compute units");
+    HIPCHK(c, hipDeviceSynchronize());
+    c->ncu = n == 0 ? c->ncu_dev : n;
+    c->plan_bits = nullptr;                          // (the stored plan was made for another number of workgroups)
     return SB_OK;
 }
 

@@ -105,6 +105,10 @@ class Context:
         """The strip kernel keeps its plan while the band plane stands (default) or plans every call (measurement / test knob)."""
         self._chk(self.lib.sb_set_plan_cache(self.h, C.c_int(1 if on else 0)), "sb_set_plan_cache")
 
+    def set_workgroups(self, n: int):
+        """Persistent workgroups of the one-per-CU kernels (0: the device's compute units); a test knob."""
+        self._chk(self.lib.sb_set_workgroups(self.h, C.c_int(int(n))), "sb_set_workgroups")
+
     def set_band_order(self, contrast_first: bool):
         """A band step runs k_scan, k_wind | join | contrast (default) or k_scan | join | contrast, k_wind (measurement knob)."""
         self._chk(self.lib.sb_set_band_order(self.h, C.c_int(1 if contrast_first else 0)), "sb_set_band_order")

@@ -110,6 +110,52 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma, c
         ctx.close()
 
 
+def test_band_step_with_one_workgroup(oracles):
+    """A band step whose strip kernel marches in several rounds (one persistent workgroup, sb_set_workgroups): no plan is
+    stored for such a share, so the update behind the march walks the workgroup's blocks instead of its cell lists."""
+    from seabreeze_param_amd import synth
+    nx, ny, nz, h = 1024, 384, 2, 6
+    dt, orc = np.float64, oracles[8]
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=900.0, kwin=h - 1)
+    cdist[np.abs(cdist) > 180.0] = 12000.0
+    p = synth.pressure_3d(st, nz, dt)
+    ctx = hip.Context(0)
+    try:
+        ctx.set_search_radius_hint(h)
+        ctx.set_workgroups(1)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def frame(a):
+            f = torch.zeros((ny + 2 * h, nx + 2 * h), dtype=torch.float64, device="cuda")
+            f[h:h + ny, h:h + nx] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            torch.cuda.synchronize()
+            ctx.swap_bounds_dev(dt, f.data_ptr(), nx, ny, h, stream)
+            ctx.synchronize()
+            return f
+
+        z, sg, mk = frame(st.z), frame(st.sigma), frame(cdist)
+        pd = torch.from_numpy(p).cuda()
+        state = [torch.zeros((ny, nx), dtype=torch.float64, device="cuda") for _ in range(4)]
+        ref = [np.zeros((ny, nx)) for _ in range(4)]
+        for tn in (1, 2, 3):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            thf, ud, vd = frame(th), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+            torch.cuda.synchronize()
+            ctx.band_seabreeze_diag_dev(dt, 5400.0, tn, nx, ny, nz, h, pd.data_ptr(), ud.data_ptr(), vd.data_ptr(),
+                                        thf.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
+                                        *[s.data_ptr() for s in state], stream)
+            ctx.synchronize()
+            orc.seabreeze_diag(5400.0, tn, p, u, v, th, cdist, st.z, st.sigma, *ref, halo=0, bnd=1)
+            for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
+                err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
+                assert err < 1e-7, f"step {tn} {nm}: {err}"
+    finally:
+        ctx.close()
+
+
 def test_band_step_follows_a_changing_coast(oracles):
     """From its second step on a band step runs no k_prep: k_wind takes the segment lists the strip kernel of the step
     before compacted, unless k_scan finds the planes changed in this very step -- then its waves walk the plane itself.

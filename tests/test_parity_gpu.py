@@ -215,6 +215,34 @@ def test_stored_plan_follows_the_planes(hipctx, oracles, flavour):
             _assert_close64(a, b, f"{flavour} call {tn} state {nm}")
 
 
+@pytest.mark.parametrize("nwg", [1, 3])
+def test_few_workgroups_march_in_rounds(hipctx, oracles, nwg):
+    """With one or three persistent workgroups (sb_set_workgroups, a test knob) the strip kernel's shares of a 1024x768
+    grid hold hundreds of active blocks: several rounds of its schedule, planned anew every call (a share of several
+    rounds is not stored) -- the path that only grids far beyond the BASELINE sizes take with a workgroup per CU.
+    Same results as ever, call by call."""
+    nx, ny, nz = 1024, 768, 2
+    dt, orc = np.float64, _omp_oracle(8)
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac, rule=1, bnd=1)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=180.0, kwin=6)
+    cdist[np.abs(cdist) > 180.0] = 12000.0
+    p = synth.pressure_3d(st, nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    hipctx.set_search_radius_hint(16)
+    hipctx.set_workgroups(nwg)
+    try:
+        for tn in (1, 2, 3):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1, omp=True)
+            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+            for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+                _assert_close64(a, b, f"{nwg} workgroups tn={tn} {nm}")
+    finally:
+        hipctx.set_workgroups(0)
+
+
 def test_alternating_grids_and_contrast_kernels_in_one_context(hipctx, oracles):
     """Twenty calls that alternate between two grids and between the strip kernel (halo 16) and the tile kernel (halo 24)
     inside ONE context: every switch re-sizes the block-flag buffers, whose zeroing once ran on the null stream --
