@@ -215,7 +215,7 @@ def test_stored_plan_follows_the_planes(hipctx, oracles, flavour):
             _assert_close64(a, b, f"{flavour} call {tn} state {nm}")
 
 
-@pytest.mark.parametrize("nwg", [1, 3])
+@pytest.mark.parametrize("nwg", [1, 3, 4, 5])
 def test_few_workgroups_march_in_rounds(hipctx, oracles, nwg):
     """With one or three persistent workgroups (sb_set_workgroups, a test knob) the strip kernel's shares of a 1024x768
     grid hold hundreds of active blocks: several rounds of its schedule, planned anew every call (a share of several
