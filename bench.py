@@ -28,9 +28,19 @@ import sys
 import time
 
 import numpy as np
-
+# torch BEFORE the library is loaded: PyTorch bundles a HIP runtime and loads it by path, libseabreeze_hip.so asks for
+# the soname -- in this order the library binds to the runtime torch brought and the process has ONE runtime, so torch's
+# stream handle is a valid hipStream_t for the C ABI and torch.cuda.synchronize() sees the library's kernels.  The run
+# does not rely on it: `hip.hip_runtimes()` is checked below, named in config.hip_runtime, and with two runtimes the
+# library runs on its own stream and every timed region closes with the library's synchronisation as well.
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if os.environ.get("SEABREEZE_BENCH_LIBRARY_FIRST"):
+    # test knob (tests/test_bench_contract_gpu.py): the OTHER load order -- the library brings /opt/rocm's runtime,
+    # torch then adds its own; the run must give the same results and an honest time
+    from seabreeze_param_amd import hip as _hip_first
+    _hip_first.load_library()
+import torch  # noqa: E402,F401
 
 from seabreeze_param_amd import hip, synth  # noqa: E402
 from seabreeze_param_amd.bands import BandRunner, row_cost, split_rows  # noqa: E402
@@ -120,37 +130,26 @@ def cpu_baseline_and_parity(st, cdist, p, u, v, thetas, nz, gpu_states, timestep
         # 290 K sequentially in fp32 and carries ~6e-4 K of rounding noise in thc (tests/fp32_tolerance_study.py),
         # more than the HIP path's error, so it cannot serve as the yardstick.  Tolerances as in
         # tests/test_parity_gpu.py::test_baseline_config3_fp32_vs_oracle.
+        from oracle import fp32_criterion as crit          # the rule tests/test_parity_gpu.py holds configs[3] to as well
         orc8 = Oracle(8, omp=True)
         f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         state = [np.zeros((ny, nx), np.float64) for _ in range(4)]
         cd8, z8, sg8 = f8(cdist), f8(st.z), f8(st.sigma)
         band = np.abs(cd8) <= 180.0
-        worst = {"windspeed_rel": 0.0, "winddir_abs_deg": 0.0, "thc_abs_K": 0.0, "sb_con_rel_away_from_thresholds": 0.0}
-        flips = triggered = 0
+        g_prev = [np.zeros((ny, nx), np.float32) for _ in range(4)]
+        per_step = []
         for (tn, inputs), gstate in zip(gpu_states["steps"], gpu_states["states"]):
             pp, uu, vv, th = inputs
+            o_prev = [a.copy() for a in state]
             orc8.seabreeze_diag(timestep, tn, f8(pp), f8(uu), f8(vv), f8(th), cd8, z8, sg8, *state, halo=0, bnd=1, omp=True)
-            g = [a.astype(np.float64) for a in gstate]
-            worst["windspeed_rel"] = max(worst["windspeed_rel"], relerr(g[0][band], state[0][band]))
-            dd = np.abs(g[1][band] - state[1][band])
-            worst["winddir_abs_deg"] = max(worst["winddir_abs_deg"], float(np.minimum(dd, 360.0 - dd).max()))
-            worst["thc_abs_K"] = max(worst["thc_abs_K"], float(np.abs(g[2][band] - state[2][band]).max()))
-            # sb_con = (|thc| - 0.75) / thc * scale_wind: an error d in thc becomes a relative error d / (|thc| - 0.75) in
-            # sb_con, so "away from the threshold" is measured in units of this step's own worst thc error -- cells
-            # within (that error) / (the sb_con tolerance) of 0.75 are left to the flip count below
-            margin = float(np.abs(g[2][band] - state[2][band]).max()) / 5e-4
-            both = band & (g[3] != 0) & (state[3] != 0) & (np.abs(np.abs(state[2]) - 0.75) > margin)
-            if both.any():
-                worst["sb_con_rel_away_from_thresholds"] = max(worst["sb_con_rel_away_from_thresholds"],
-                                                               relerr(g[3][both], state[3][both]))
-            flips += int(((g[3] != 0) != (state[3] != 0)).sum())
-            triggered += int((state[3] != 0).sum())
-        tol = {"windspeed_rel": 5e-6, "winddir_abs_deg": 1e-3, "thc_abs_K": 2e-4, "sb_con_rel_away_from_thresholds": 5e-4}
-        parity = {"max_err": worst, "tolerance": tol, "steps": [tn for tn, _ in gpu_states["steps"]],
-                  "trigger_flips": flips, "triggered_cells_fp64": triggered,
-                  "checker": "oracle/sb_oracle.f90 in DOUBLE precision on the same fp32-representable inputs (the reference's "
-                             "own fp32 arithmetic carries ~6e-4 K of window-sum noise: tests/fp32_tolerance_study.py)",
-                  "ok": bool(all(worst[k] <= tol[k] for k in tol) and flips <= max(2, triggered // 2000))}
+            per_step.append(crit.check_step(tn, g_prev, gstate, o_prev, state, band, timestep=timestep))
+            g_prev = gstate
+        parity = crit.merge(per_step)
+        parity["steps"] = [tn for tn, _ in gpu_states["steps"]]
+        parity["checker"] = ("oracle/sb_oracle.f90 in DOUBLE precision on the same fp32-representable inputs (the reference's "
+                             "own fp32 arithmetic carries ~6e-4 K of window-sum noise: tests/fp32_tolerance_study.py); sb_con by "
+                             "per-cell error propagation from the measured thc and wind errors, no cell masked "
+                             "(oracle/fp32_criterion.py)")
     # ---- timing -----------------------------------------------------------------------------------
     out = {}
     for name, omp in (("serial", False), ("omp", True)):
@@ -214,20 +213,28 @@ def time_setup_kernels(ctx, torch, st, coast, dt, kwin, reps=5):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
     lf, ic, co = up(st.landfrac), up(st.icefrac), up(coast)
     out = torch.empty_like(lf)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = hip.torch_stream_handle(torch)
     ny, nx = st.ny, st.nx
     esz = np.dtype(dt).itemsize
     res = {}
 
     def timed(fn):
         ts = []
+        fn()                                            # (untimed: tables and workspace of the first call)
         for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            if stream is not None:                      # one HIP runtime: events on the stream the kernels run on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            else:                                       # two runtimes: the library's own stream, host clock round a synchronised call
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                ctx.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
         return float(np.median(ts))
 
     ms = timed(lambda: ctx.get_edges_dev(dt, nx, ny, lf.data_ptr(), ic.data_ptr(), out.data_ptr(), stream=stream))
@@ -267,7 +274,6 @@ def main():
                     help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
     args = ap.parse_args()
 
-    import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,6 +301,8 @@ def main():
 
     nx, ny, nz = args.nx, args.ny, args.nz
     dt = np.float64 if args.dtype == "f64" else np.float32
+    # which BASELINE.json configuration this run is (None: a grid / precision BASELINE.json does not name)
+    cfg_index = {(1024, 768, "f64"): 1, (2560, 1920, "f64"): 2, (5120, 3840, "f32"): 3}.get((nx, ny, args.dtype))
     esz = 8 if args.dtype == "f64" else 4
     K, W = args.steps, args.warmup
 
@@ -302,6 +310,8 @@ def main():
     t_gen = time.perf_counter()
     st = synth.static_fields(nx, ny, dt)
     ctx = hip.Context(local_rank)
+    runtimes = hip.hip_runtimes()
+    shared_runtime = len(runtimes) == 1
     if args.no_fold:
         ctx.set_fold(False)
     if world > 1 and comm == "native":
@@ -364,7 +374,7 @@ def main():
         gpu_states = {"steps": [], "states": []}
         for tn in (1, 2, 15):
             runner.step(timestep, tn, sets[tn % NSET])
-            torch.cuda.synchronize()
+            runner.synchronize()
             gpu_states["steps"].append((tn, host_sets[tn % NSET]) if world == 1 else (tn, tn % NSET))
             gpu_states["states"].append([t.cpu().numpy().copy() for t in (runner.ws, runner.wd, runner.thc, runner.sb_con)])
     band_check = None
@@ -377,43 +387,68 @@ def main():
         dist.all_reduce(red[4:], op=dist.ReduceOp.SUM)
         band_check = [float(x) for x in red.cpu()]
 
-    tn = 1
-    for _ in range(W):
-        runner.step(timestep, tn, sets[tn % NSET]); tn += 1
-    torch.cuda.synchronize(); barrier()
+    def timed_pass(tn, warm):
+        """W untimed steps, then exactly K steps between barrier + synchronisation (of the library's context and of
+        torch's device, whichever runtime each lives in) on both sides; the maximum over ranks."""
+        for _ in range(warm):
+            runner.step(timestep, tn, sets[tn % NSET]); tn += 1
+        runner.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            runner.step(timestep, tn, sets[tn % NSET]); tn += 1
+        runner.synchronize(); barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, tn
 
     events_inside = args.profile_passes == 0
-    if events_inside:
+    tn = 1
+    if events_inside:                                   # (the PMC passes: events of the K timed steps only)
+        for _ in range(W):
+            runner.step(timestep, tn, sets[tn % NSET]); tn += 1
+        runner.synchronize()
         ctx.profile_begin(K)
-    torch.cuda.synchronize(); barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        runner.step(timestep, tn, sets[tn % NSET]); tn += 1
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, tn = timed_pass(tn, 0)
+    else:
+        elapsed, tn = timed_pass(tn, W)
 
-    # ---- per-step HIP-event times (median): a K-step pass of its own -----------------
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
-    evs[0].record()
-    for i in range(K):
-        runner.step(timestep, tn, sets[tn % NSET]); tn += 1
-        evs[i + 1].record()
-    torch.cuda.synchronize()
-    step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(K)])
-    median_ms = float(np.median(step_ms))
+    # ---- per-step HIP-event times (median, BASELINE.md §3): a K-step pass of its own; only where torch's events sit
+    # on the stream the kernels run on (one HIP runtime) ---------------------------------------------------------
+    median_ms = None
+    if shared_runtime:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        evs[0].record()
+        for i in range(K):
+            runner.step(timestep, tn, sets[tn % NSET]); tn += 1
+            evs[i + 1].record()
+        runner.synchronize()
+        step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(K)])
+        median_ms = float(np.median(step_ms))
 
-    # ---- per-kernel HIP-event timing (same stream, same inputs, live in this run) -------
+    # ---- per-kernel HIP-event timing (the library's own events on the stream its kernels run on) -------
     if not events_inside:
         ctx.profile_begin(K * args.profile_passes)
         for _ in range(K * args.profile_passes):
             runner.step(timestep, tn, sets[tn % NSET]); tn += 1
     kern_ms, ncalls = ctx.profile_end()
     counters = ctx.last_counters()
+
+    # ---- the same K steps with the contrast kernel's plan remade in every call (sb_set_plan_cache(0)): what a first
+    # call, or a call after the ice edge moved, costs.  The headline above is the stored-plan state. -------------
+    replan = None
+    if world == 1:
+        ctx.set_plan_cache(False)
+        el_r, tn = timed_pass(tn, W)
+        ctx.profile_begin(K)
+        for _ in range(K):
+            runner.step(timestep, tn, sets[tn % NSET]); tn += 1
+        kr, _ = ctx.profile_end()
+        ctx.set_plan_cache(True)
+        replan = {"ms_per_step": el_r / K * 1e3, "k_thc": round(kr["k_thc"], 5), "steps": K,
+                  "what": "sb_set_plan_cache(ctx, 0): shares, schedule, cell lists, radius search in every call"}
 
     ms_per_step = elapsed / K * 1e3
     value = nx * ny / (elapsed / K)
@@ -438,7 +473,7 @@ def main():
         "warmup": W,
         "ms_per_step": ms_per_step,
         "median_ms_per_step": median_ms,
-        "value_median": nx * ny / (median_ms * 1e-3),
+        "value_median": nx * ny / (median_ms * 1e-3) if median_ms else None,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -446,7 +481,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"seabreeze_diag generic flavour, N{nx // 2} ({nx}x{ny}) global grid, nz={nz}, {'fp64' if esz == 8 else 'fp32'} "
-                        f"(BASELINE.json configs[2])",
+                        + (f"(BASELINE.json configs[{cfg_index}])" if cfg_index is not None else "(not a BASELINE.json configuration)"),
+            "baseline_config_index": cfg_index,
+            "hip_runtime": runtimes,
+            "stream": ("torch's current stream (torch and the library share one HIP runtime)" if shared_runtime else
+                       "the library context's own stream (two HIP runtimes in the process; timed regions close with both synchronisations)"),
+            "plan_cache": "stored",
             "nx": nx, "ny": ny, "nz": nz,
             "band_fraction": n_band_total / (nx * ny),
             "search_halo": kwin + 1,
@@ -473,6 +513,8 @@ def main():
             "limiting": {"kernel": lim, "frac": fracs[lim]} if lim else None,      # the kernel furthest below its roofline
             "event_calls": ncalls,
             "whole_call": {"algorithmic_bytes": ab["total"], "achieved": call_gbs, "frac": call_gbs / HBM_PEAK_GBS},
+            "plan_cache": "stored",
+            "replan": replan,
             "rank0_counters": counters,
         },
     }

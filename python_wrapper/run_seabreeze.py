@@ -25,6 +25,7 @@ def main(config, verbose=True):
     thc, windspeed, winddir = (np.zeros(shape) for _ in range(3))
     tt = 1
     written = []
+    result = None                   # one (ntime, lat, lon) result array for all files of equal length (diag's out=)
     for stamp in meta.dates:
         f_sb = meta.input_file("sb", stamp)
         if verbose:
@@ -33,8 +34,11 @@ def main(config, verbose=True):
         data = sbd.read_nc(files["vv"], files["vu"], files["vtheta"], files["vci"], vv=cfg.vv, vu=cfg.vu,
                            vtheta=cfg.vtheta, vci=cfg.get("vci", "ci"), vpres=cfg.vpres, vtime=cfg.vtime)
         try:
+            nt = data.v.shape[0]
+            if result is None or result.shape[0] != nt:
+                result = np.empty((nt,) + shape)
             tt, sb_con, thc, windspeed, winddir = sbd.diag(tt, meta.landfrac, meta.z, meta.std, meta.lon, meta.lat,
-                                                           data.pres, meta=data, ws=windspeed, wd=winddir, thc=thc)
+                                                           data.pres, meta=data, ws=windspeed, wd=winddir, thc=thc, out=result)
             meta.create_nc(sb_con, f_sb, "sb_con", data.time)
         finally:
             for f in data.nc.values():

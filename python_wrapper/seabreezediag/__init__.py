@@ -117,7 +117,9 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
 
     Positional: ``tt, lsm, z, std, lon, lat, pres, u, v, t, ci`` -- or pass ``meta=`` (an
     object with attributes ``u, v, theta`` and optionally ``ci``) instead of the last four.
-    Keywords: state ``ws, wd, thc`` from the previous call (default zeros), plus the kernel
+    Keywords: state ``ws, wd, thc`` from the previous call (default zeros); ``out`` -- a float64
+    ``(ntime, lat, lon)`` array to receive ``sb_con`` in place of a fresh one (not in the reference;
+    every plane is overwritten); plus the kernel
     tunables ``target_plev`` [hPa], ``thresh_wind``, ``thresh_winddir``, ``thresh_windch``,
     ``thresh_thc``, ``target_time`` [h], ``maxdist`` [km], ``timestep`` [min].
 
@@ -125,6 +127,7 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
     """
     ws, wd, thc = (_pop(kwargs, k) for k in ("ws", "wd", "thc"))
     meta = _pop(kwargs, "meta")
+    out_arr = _pop(kwargs, "out")
     if meta is None:
         u, v, t, ci = args
     else:
@@ -151,11 +154,19 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
     has_time = len(shape_of(v)) > 3
     nt = shape_of(v)[0] if has_time else 1
     nlat, nlon = shape_of(t)[-2:]
-    sb_all = np.zeros([nt, nlat, nlon])           # float64 like the reference's (ref :214)
+    if out_arr is None:
+        sb_all = np.zeros([nt, nlat, nlon])       # float64 like the reference's (ref :214)
+    else:
+        # the caller's result array, written in place and returned (a driver that steps through many chunks hands the
+        # same array in again and pays the page faults of a fresh (nt, lat, lon) float64 array once, not per chunk)
+        if not (isinstance(out_arr, np.ndarray) and out_arr.dtype == np.float64 and out_arr.shape == (nt, nlat, nlon)
+                and out_arr.flags.c_contiguous and out_arr.flags.writeable):
+            raise ValueError(f"out= must be a writeable C-contiguous float64 array of shape {(nt, nlat, nlon)}")
+        sb_all = out_arr
     dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
 
     static_seen = [False]
-    last_ice = [None]                                        # (address, shape, strides) of the ice plane of the step before
+    last_ice = [None]                                        # the ice plane of the step before, where it is PROVABLY this one
 
     def step_inputs(ts):
         nonlocal dist
@@ -164,13 +175,17 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
             ice = ice.filled(0) if hasattr(ice, "filled") else ice
             ice = np.asarray(ice, dtype=np.float32)          # what f2py would make of it (file data may be big-endian)
             # the reference recomputes it every step (:223-228); here: when the ice changes.  lsm, lon, lat are this
-            # call's arguments: compared with the kept copies at the first step only.  A plane that lies where the
-            # plane of the step before lay (a broadcast, or no time axis) is that plane: nothing runs between the
-            # steps of one call that could have written it -- no comparison (0.3 ms at 1024 x 768) either.
-            where = (ice.__array_interface__["data"][0], ice.shape, ice.strides)
-            if not (static_seen[0] and where == last_ice[0]):
+            # call's arguments: compared with the kept copies at the first step only.  The comparison of the ice plane
+            # itself (0.3 ms at 1024 x 768) is skipped only where the plane is provably the memory of the step before:
+            # `ci` is an array the CALLER holds (so it outlives this loop and no reader refills it between steps) and
+            # this step's plane is the same window into it -- a broadcast time axis, or no time axis.  An equal address
+            # alone proves nothing: a file reader hands out views of per-read temporaries (netCDF4's `data[...]`, a
+            # nomask MaskedArray's `filled()`), and the next read may land where the last one was freed.
+            provable = isinstance(ci, np.ndarray) and np.may_share_memory(ice, ci)
+            where = (ice.__array_interface__["data"][0], ice.shape, ice.strides) if provable else None
+            if not (static_seen[0] and where is not None and where == last_ice[0]):
                 dist = _coast_distance(lsm, ice, lon, lat, static_known_same=static_seen[0])
-            last_ice[0] = where if ice.base is not None or ice is ci else None      # (a temporary's address may be reused)
+            last_ice[0] = where
             static_seen[0] = True
         return (t[ts], v[ts], u[ts]) if has_time else (t[:], v[:], u[:])
 

@@ -129,6 +129,17 @@ class BandRunner:
             ctx.use_gathered_moments(self.gath.data_ptr(), world)
         ctx.set_search_radius_hint(halo)
 
+    # -- streams -----------------------------------------------------------------------
+    def _stream(self):
+        """torch's current stream when torch and the library share one HIP runtime (torch imported before the library
+        was loaded), else None: the library then runs on its context's own stream (hip.torch_stream_handle)."""
+        return _hip.torch_stream_handle(self.torch)
+
+    def synchronize(self):
+        """Everything this runner enqueued has finished, whichever runtime and stream ran it."""
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
     # -- uploads -----------------------------------------------------------------------
     def _halo_field(self, full2d):
         """Interior rows of this band inside a ghost-cell frame (ghosts zero until exchanged)."""
@@ -141,8 +152,7 @@ class BandRunner:
     def _fill_ghosts(self, loc):
         if self.world > 1:
             if self.comm == "native":
-                self.ctx.swap_bounds_dev(self.dtype, loc.data_ptr(), self.nx, self.nyl, self.h,
-                                         self.torch.cuda.current_stream().cuda_stream)
+                self.ctx.swap_bounds_dev(self.dtype, loc.data_ptr(), self.nx, self.nyl, self.h, self._stream())
             else:
                 exchange_ns(loc, self.nyl, self.h, self.rank, self.world, self.dist, self.torch)
                 fill_ew_ghosts(loc, self.nx, self.h)
@@ -170,7 +180,7 @@ class BandRunner:
     # -- one model step -------------------------------------------------------------------
     def step(self, timestep: float, tn: int, s):
         t = self.torch
-        stream = t.cuda.current_stream().cuda_stream
+        stream = self._stream()
         if self.world > 1 and self.comm == "native":
             # one C-ABI call: communication on the library's second stream under k_scan/k_wind
             self.ctx.band_seabreeze_diag_dev(self.dtype, timestep, tn, self.nx, self.nyl, self.nz, self.h,

@@ -52,6 +52,32 @@ def load_library() -> C.CDLL:
     return _lib
 
 
+def hip_runtimes():
+    """Paths of the HIP runtimes (libamdhip64) mapped into this process.  PyTorch bundles a runtime of its own and
+    loads it by path; libseabreeze_hip.so asks for the soname.  So with `import torch` FIRST the library binds to
+    torch's copy and the process has ONE runtime -- a torch stream handle is then a valid hipStream_t for the C ABI --
+    while with the library loaded first there are TWO, whose streams and synchronisation know nothing of each other."""
+    seen = []
+    try:
+        for ln in open("/proc/self/maps"):
+            i = ln.find("/")
+            path = ln[i:].strip() if i >= 0 else ""
+            if "libamdhip64.so" in path and path not in seen:
+                seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def torch_stream_handle(torch):
+    """The hipStream_t to hand to the `_dev` entry points from a process that also runs PyTorch: torch's current
+    stream when torch and the library share one HIP runtime, else None (NULL = the context's own stream; the caller
+    must then close every hand-over with Context.synchronize() AND torch.cuda.synchronize())."""
+    if len(hip_runtimes()) == 1:
+        return torch.cuda.current_stream().cuda_stream
+    return None
+
+
 def _p(a):
     if a is None:
         return None

@@ -616,22 +616,30 @@ def test_baseline_config3_fp32_vs_oracle(hipctx):
     cdist = hipctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     assert hip.dist_window(st.lon, st.lat) == 30
     p = synth.pressure_3d(st, nz, dt)
+    from oracle import fp32_criterion as crit          # the same rule as bench.py's parity leg
     so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
     s8 = _states(ny, nx, np.float64, 4)
     f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    for tn in (1, 2):
+    band = np.abs(f8(cdist)) <= 180.0
+    per_step = []
+    for tn in (1, 2, 15):
         th = synth.theta_step(st, tn, dt)
         u, v = synth.wind_step(st, nz, tn, dt)
+        g_prev, o_prev = [a.copy() for a in sh], [a.copy() for a in s8]
         orc4.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1, omp=True)
         orc8.seabreeze_diag(1440.0, tn, f8(p), f8(u), f8(v), f8(th), f8(cdist), f8(st.z), f8(st.sigma), *s8, halo=0, bnd=1, omp=True)
         hipctx.seabreeze_diag(1440.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        # winds against the fp32 oracle (no window sum in them) ...
         assert relerr(sh[0], so[0], floor=1e-3) < 2e-6 and relerr(sh[1], so[1], floor=1e-1) < 2e-5, tn
+        # ... the contrast against the fp64 arithmetic, and closer to it than the reference's own fp32 arithmetic is
         e_hip = float(np.max(np.abs(sh[2].astype(np.float64) - s8[2])))
         e_ref = float(np.max(np.abs(so[2].astype(np.float64) - s8[2])))
-        assert e_hip < 2e-4, (tn, e_hip, e_ref)
         assert e_hip < e_ref and np.max(np.abs(sh[2] - so[2])) < 0.1, (tn, e_hip, e_ref)
-        near = np.abs(np.abs(s8[2]) - 0.75) < 1e-3
-        assert np.max(np.abs(sh[3].astype(np.float64) - s8[3])[~near]) < 1e-3, tn
+        per_step.append(crit.check_step(tn, g_prev, sh, o_prev, s8, band, timestep=1440.0))
+    res = crit.merge(per_step)
+    # every input of the trigger within its fp32 tolerance, sb_con within what those input errors explain in each cell
+    # (no cell masked), no flip that a knife edge does not explain
+    assert res["ok"] and res["masked_cells"] == 0 and res["cells_compared"] > 10 ** 6, res
     c = hipctx.last_counters()
     assert c["global_path_cells"] == 0 and 24 < c["max_radius"] <= 32, c
 

@@ -128,6 +128,68 @@ def test_coast_distance_is_reused_while_its_inputs_are_unchanged(monkeypatch):
     assert [float(sb[i].max()) for i in range(nt)] == [1.0, 1.0, 2.0, 2.0]
 
 
+class _TempBackedIce:
+    """A file-variable stand-in: every read allocates a fresh buffer and hands out a VIEW of it (like a squeezed
+    netCDF4 `data[...]`, or a nomask MaskedArray's `filled()`); the buffer dies with the step, and the next read
+    usually lands at the same address."""
+
+    def __init__(self, planes, masked):
+        self.planes, self.masked, self.shape = planes, masked, planes.shape
+
+    def __getitem__(self, ts):
+        buf = np.empty((1,) + self.planes.shape[1:], np.float32)
+        buf[0] = self.planes[ts]
+        view = buf[0]                                   # base is not None
+        return np.ma.MaskedArray(view) if self.masked else view
+
+
+@pytest.mark.skipif(not _built(), reason="python_wrapper extension not built")
+@pytest.mark.parametrize("masked", [False, True])
+def test_ice_from_a_reader_of_temporaries_is_compared_every_step(monkeypatch, masked):
+    """The ice plane of a step may lie at the address the plane of the step before was freed at: an equal address must
+    not stand in for an equal content (round 3's shortcut did that and kept a stale distance field).  Host logic only."""
+    _, sbd = _import_surface()
+    calls = {"dist": 0}
+
+    def fake_dist(coast, mask, lon, lat):
+        calls["dist"] += 1
+        return np.asfortranarray(np.full(coast.shape, float(calls["dist"]), np.float32))
+
+    def fake_diag(tt, p, z, std, t, v, u, dist, ws, wd, thc, **kw):
+        out = np.zeros(z.shape + (4,), np.float32, order="F")
+        out[..., 0] = dist
+        return out
+
+    monkeypatch.setattr(sbd, "get_edges", lambda lsm, ci: np.asfortranarray(np.zeros(lsm.shape, np.float32)))
+    monkeypatch.setattr(sbd, "get_dist", fake_dist)
+    monkeypatch.setattr(sbd, "_diag_kernel", fake_diag)
+    monkeypatch.setattr(sbd, "_HAVE_STREAM", False)
+    monkeypatch.setitem(sbd._dist_cache, "key", None)
+    nt, nlev, nlat, nlon = 5, 2, 6, 8
+    lsm = np.zeros((nlat, nlon), np.float32)
+    lon, lat = np.arange(nlon, dtype=np.float32), np.arange(nlat, dtype=np.float32)
+    pres = np.array([1000., 700.], np.float32)
+    u = v = np.zeros((nt, nlev, nlat, nlon), np.float32)
+    t = np.zeros((nt, nlat, nlon), np.float32)
+    planes = np.stack([np.full((nlat, nlon), 0.1 * k, np.float32) for k in (0, 1, 1, 2, 3)])   # changes at steps 2, 4, 5
+    tt, sb, *_ = sbd.diag(1, lsm, lsm, lsm, lon, lat, pres, u, v, t, _TempBackedIce(planes, masked))
+    assert calls["dist"] == 4
+    assert [float(sb[i].max()) for i in range(nt)] == [1.0, 2.0, 2.0, 3.0, 4.0]
+    # ... while a plane that provably IS the plane of the step before (the caller's own array, broadcast in time) is not
+    # even compared: one computation, and `out=` receives the result in place
+    monkeypatch.setitem(sbd._dist_cache, "key", None)
+    calls["dist"] = 0
+    compared = {"n": 0}
+    same = sbd._same
+    monkeypatch.setattr(sbd, "_same", lambda a, b: (compared.__setitem__("n", compared["n"] + 1), same(a, b))[1])
+    mine = np.empty((nt, nlat, nlon))
+    tt, sb, *_ = sbd.diag(1, lsm, lsm, lsm, lon, lat, pres, u, v, t, np.broadcast_to(planes[1], (nt, nlat, nlon)), out=mine)
+    assert sb is mine and calls["dist"] == 1 and compared["n"] == 0
+    assert [float(mine[i].max()) for i in range(nt)] == [1.0] * nt
+    with pytest.raises(ValueError):
+        sbd.diag(1, lsm, lsm, lsm, lon, lat, pres, u, v, t, planes, out=np.empty((nt, nlat, nlon), np.float32))
+
+
 def _stream_case(nt, nlat, nlon, nlev, seed=5, ice_change_at=None):
     """Synthetic inputs in the reference driver's conventions: C-ordered (lat, lon), winds (time, pres, lat, lon)."""
     from seabreeze_param_amd import synth

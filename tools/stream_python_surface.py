@@ -38,6 +38,7 @@ th = np.stack([synth.theta_step(st, t, dt) for t in range(1, chunk + 1)])
 ice0 = st.icefrac.astype(dt)
 out_json = sys.argv[6] if len(sys.argv) >= 7 else None
 tt, ws, wd, thc = 1, None, None, None
+result = np.empty((chunk, nlat, nlon))                           # one result array for every chunk (diag's out=)
 t0 = time.perf_counter()
 done = 0
 split = np.zeros(3)
@@ -46,7 +47,7 @@ while done < nsteps:
     day = done // 60                                             # 24-minute steps: 60 per day
     ci = np.broadcast_to(np.clip(ice0 + 0.01 * (day % 3), 0, 1).astype(dt), (chunk, nlat, nlon))
     kw = {} if ws is None else dict(ws=ws, wd=wd, thc=thc)
-    tt, sb, thc, ws, wd = sbd.diag(tt, lsm, z, std, st.lon.astype(dt), st.lat.astype(dt), pres, u, v, th, ci, **kw)
+    tt, sb, thc, ws, wd = sbd.diag(tt, lsm, z, std, st.lon.astype(dt), st.lat.astype(dt), pres, u, v, th, ci, out=result, **kw)
     done += chunk
     n, parts = sbd.stream_stats()
     streamed += int(n)
