@@ -107,6 +107,7 @@ class BandRunner:
         assert comm in ("torch", "native")
         self.static_sigma = bool(static_sigma)
         self._stats_done = False
+        self._shared_runtime = None
         ctx.set_static_sigma(self.static_sigma)
         self.comm = comm
         self.ctx, self.torch, self.dist = ctx, torch, dist
@@ -133,7 +134,9 @@ class BandRunner:
     def _stream(self):
         """torch's current stream when torch and the library share one HIP runtime (torch imported before the library
         was loaded), else None: the library then runs on its context's own stream (hip.torch_stream_handle)."""
-        return _hip.torch_stream_handle(self.torch)
+        if self._shared_runtime is None:                # (reading the process's maps is not a per-step affair)
+            self._shared_runtime = len(_hip.hip_runtimes()) == 1
+        return self.torch.cuda.current_stream().cuda_stream if self._shared_runtime else None
 
     def synchronize(self):
         """Everything this runner enqueued has finished, whichever runtime and stream ran it."""

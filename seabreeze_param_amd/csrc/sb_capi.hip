@@ -104,6 +104,10 @@ class HostPool {
     bool quit_ = false;
 };
 
+// words of sb_ctx::ticket: [0] k_scan's spare word, [1] k_stats' / a band step's ticket, [2..7] the fused kernel's two
+// barrier words and fill counter (three per launch, alternating launches), [8] barrier waits that gave up
+enum { SB_TICKET_FUSE = 2, SB_TICKET_FUSE_ERR = 8, SB_TICKET_WORDS = 12 };
+
 struct DiagStream {
     bool active = false;
     HostPool *pool = nullptr;                  // created by the first sb_diag_stream_begin, joined by sb_destroy
@@ -131,6 +135,8 @@ struct sb_ctx {
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
     int no_plan_cache = 0;              // sb_set_plan_cache(ctx, 0): the strip kernel plans its march afresh every call
+    int no_fuse = 0;                    // sb_set_fuse(ctx, 0): k_scan and the strip kernel as two launches
+    unsigned fuse_seq = 0;              // fused launches so far: their barrier words alternate
     int band_late_wind = 0;             // sb_set_band_order(ctx, 1): a band step runs the contrast before k_wind (measurement)
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
@@ -369,12 +375,27 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const bool strip_folds = strip && job.t0_fly && !c->no_fold;
     lc.segs_stand = strip_folds && c->gathered && c->plan_use && c->segs_built && !c->no_plan_cache;
     job.fold = 0; job.fold_partials = nullptr; job.fold_nparts = 0; job.stats_out = nullptr;
+    // (single-domain calls: the lists the strip kernel of the call before compacted belong to the same planes as its plan)
+    job.lists_stand = (strip_folds && !c->gathered && phases == 3 && c->plan_use && c->segs_built && !c->no_plan_cache) ? 1 : 0;
     job.gath = nullptr; job.ngath = 0;
     int launched = 0;
     lc.launches = &launched;
+    // k_scan's pass and the march in one launch: whole single-domain host-model calls on the strip kernel, every
+    // workgroup of the grid on a compute unit of its own (they meet at a barrier inside the kernel)
+    lc.fuse = !c->no_fuse && phases == 3 && !c->gathered && strip_folds && job.wind_final && c->ncu <= c->ncu_dev && c->ncu <= 1024;
+    lc.fuse_ticket = c->ticket + SB_TICKET_FUSE + 3 * (c->fuse_seq & 1u);
+    lc.fuse_ticket_next = c->ticket + SB_TICKET_FUSE + 3 * ((c->fuse_seq + 1u) & 1u);
+    lc.fuse_err = c->ticket + SB_TICKET_FUSE_ERR;
+    if (lc.fuse) ++c->fuse_seq;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
     {
         const hipError_t le = sb_launch_diag<T>(job, Hk, lc);
+        if (le != hipSuccess) {
+            // nothing the host noted for later calls stands: the stored plan and the segment lists were not (all) made
+            c->plan_bits = nullptr;
+            c->segs_built = false;
+            c->stats_valid = false;
+        }
         if (le == hipErrorInvalidValue) return fail(c, SB_ERR_ARG, "no contrast kernel instance for this halo / tile shape");
         if (le != hipSuccess) return hipfail(c, le, "sb_launch_diag");
     }
@@ -1067,12 +1088,12 @@ int sb_create(sb_ctx **out, int device) {
         return hipfail(nullptr, e, "hipStreamCreate");
     }
     bool ok = hipMalloc((void **)&c->partials, SB_STATS_MAX_BLOCKS * sizeof(Moments)) == hipSuccess &&
-              hipMalloc((void **)&c->ticket, 2 * sizeof(unsigned int)) == hipSuccess &&     // [0] k_scan's spare word, [1] k_stats' ticket
+              hipMalloc((void **)&c->ticket, SB_TICKET_WORDS * sizeof(unsigned int)) == hipSuccess &&   // (see SB_TICKET_*)
               hipMalloc(&c->stats, 4 * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&c->counters, 2 * sizeof(int)) == hipSuccess &&
               hipMalloc((void **)&c->seg_count, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
               hipMemset(c->seg_count, 0, SB_SEG_PARTS * sizeof(int)) == hipSuccess &&
-              hipMemset(c->ticket, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
+              hipMemset(c->ticket, 0, SB_TICKET_WORDS * sizeof(unsigned int)) == hipSuccess &&
               hipMemset(c->counters, 0, 2 * sizeof(int)) == hipSuccess &&
               hipDeviceSynchronize() == hipSuccess;   // the null-stream memsets have landed before any other stream runs
     if (!ok) {
@@ -1600,6 +1621,12 @@ int sb_set_band_order(sb_ctx *c, int contrast_first) {
 int sb_set_plan_cache(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     c->no_plan_cache = on ? 0 : 1;
+    return SB_OK;
+}
+
+int sb_set_fuse(sb_ctx *c, int on) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    c->no_fuse = on ? 0 : 1;
     return SB_OK;
 }
 

@@ -297,6 +297,8 @@ struct DiagJob {
     const Moments *gath;            // band step: the moments gathered from every rank (ngath of them), merged by the first wave
     int ngath;                      //   of every k_thc3 workgroup in k_merge_moments' tree; 0: the scalars in stats stand
     int fold;
+    int lists_stand;                // the segment lists of an earlier call are in place and belong to the planes the stored plan
+                                    // belongs to: a march by that plan does not compact them again
     const Moments *fold_partials;   // k_scan's per-workgroup moments (fold_nparts of them; 0: the scalars in stats stand)
     int fold_nparts;
     T *stats_out;                   // where workgroup 0 publishes the sigmoid scalars
@@ -317,6 +319,7 @@ struct StripJob {
     int *flags;                     // strip-major block flags (DiagJob::tile_nnmax)
     int ntx, nty;                   // strips, blocks per strip
     int fold, fold_nparts, ngath, seg_cap;
+    int lists_stand;                // as DiagJob
     int update;                     // band step: thresholds and state update of this workgroup's band cells behind the march
     const T *stats;
     T *stats_out;

@@ -131,6 +131,10 @@ class Context:
         """The strip kernel keeps its plan while the band plane stands (default) or plans every call (measurement / test knob)."""
         self._chk(self.lib.sb_set_plan_cache(self.h, C.c_int(1 if on else 0)), "sb_set_plan_cache")
 
+    def set_fuse(self, on: bool):
+        """k_scan's pass and the strip kernel's march in one launch (default) or two (measurement / test knob)."""
+        self._chk(self.lib.sb_set_fuse(self.h, C.c_int(1 if on else 0)), "sb_set_fuse")
+
     def set_workgroups(self, n: int):
         """Persistent workgroups of the one-per-CU kernels (0: the device's compute units); a test knob."""
         self._chk(self.lib.sb_set_workgroups(self.h, C.c_int(int(n))), "sb_set_workgroups")

@@ -38,7 +38,7 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["kernel_ms"]["k_wind"] > 0 and rf["kernel_ms"]["k_thc"] > 0 and rf["kernel_ms"]["k_scan"] > 0
+    assert rf["kernel_ms"]["k_wind"] > 0 and rf["kernel_ms"]["k_scan_strip"] > 0 and rf["launches_per_call"] == 2
     assert d["parity"]["ok"] and max(d["parity"]["max_rel_err"].values()) < 1e-6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     # the line says which runtime ran, which stream, which BASELINE configuration (none for this grid), and which state
@@ -47,7 +47,7 @@ def test_bench_single_gpu_line():
     assert len(c["hip_runtime"]) == 1 and "torch" in c["stream"] and c["baseline_config_index"] is None
     assert "not a BASELINE.json configuration" in c["workload"] and c["plan_cache"] == "stored"
     rp = rf["replan"]
-    assert rp["ms_per_step"] > 0 and rp["k_thc"] > 0 and rf["plan_cache"] == "stored"
+    assert rp["ms_per_step"] > 0 and rp["k_scan_strip"] > 0 and rf["plan_cache"] == "stored"
 
 
 def test_bench_does_not_depend_on_the_import_order():

@@ -133,22 +133,25 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, contrast_variant):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[(16, True, True), (16, True, False), (16, False, True), (24, False, True)],
-                ids=["strip", "strip-replan", "strip-kprep", "tiles-halo24"])
+@pytest.fixture(params=[(16, True, True, True), (16, True, False, True), (16, True, True, False), (16, False, True, True), (24, False, True, True)],
+                ids=["fused", "fused-replan", "strip", "strip-kprep", "tiles-halo24"])
 def contrast_variant(request, hipctx):
     """The contrast kernels the oracle comparisons run under: the marching-strip kernel (radius hints up to 16) doing
-    k_prep's work itself (the default for host-model calls on one domain) -- with the plan of its march kept from call
-    to call (the default: the first call of a test plans, the later ones march by the stored plan) or made afresh every
-    call -- or with k_prep as a kernel of its own, and the tile kernel with its 24-cell halo (what a radius hint of
-    17..24 selects).  Results never depend on the choice."""
-    hint, fold, keep = request.param
+    k_prep's work itself and fused with k_scan's pass into one launch (the default for host-model calls on one domain)
+    -- with the plan of its march kept from call to call (the default: the first call of a test goes the long way round
+    inside the fused kernel and plans, the later ones march by the stored plan) or made afresh every call -- the same as
+    a launch of its own behind k_scan (what a band step runs), with k_prep as a kernel of its own, and the tile kernel
+    with its 24-cell halo (what a radius hint of 17..24 selects).  Results never depend on the choice."""
+    hint, fold, keep, fuse = request.param
     hipctx.set_search_radius_hint(hint)
     hipctx.set_fold(fold)
     hipctx.set_plan_cache(keep)
+    hipctx.set_fuse(fuse)
     yield hint
     hipctx.set_search_radius_hint(16)
     hipctx.set_fold(True)
     hipctx.set_plan_cache(True)
+    hipctx.set_fuse(True)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
