@@ -30,18 +30,15 @@ import time
 import numpy as np
 # torch BEFORE the library is loaded: PyTorch bundles a HIP runtime and loads it by path, libseabreeze_hip.so asks for
 # the soname -- in this order the library binds to the runtime torch brought and the process has ONE runtime, so torch's
-# stream handle is a valid hipStream_t for the C ABI and torch.cuda.synchronize() sees the library's kernels.  The run
-# does not rely on it: `hip.hip_runtimes()` is checked below, named in config.hip_runtime, and with two runtimes the
-# library runs on its own stream and every timed region closes with the library's synchronisation as well.
+# stream handle is a valid hipStream_t for the C ABI and torch.cuda.synchronize() sees the library's kernels.  In the
+# other order the process holds two runtimes, of which only the first to initialise finds the GPU (measured on this pool);
+# the run checks `hip.hip_runtimes()`, names the runtime in config.hip_runtime and refuses to time anything otherwise.
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 if os.environ.get("SEABREEZE_BENCH_LIBRARY_FIRST"):
-    # test knob (tests/test_bench_contract_gpu.py): the OTHER load order -- the library brings /opt/rocm's runtime,
-    # torch then adds its own; the run must give the same results and an honest time
+    # test knob (tests/test_bench_contract_gpu.py): the OTHER load order must end in a clear refusal, not in a number
     from seabreeze_param_amd import hip as _hip_first
     _hip_first.load_library()
-    _hip_first.get_threads()        # (its runtime initialises first: the second runtime of a process finds the device, the first
-                                    #  one to come second does not)
 import torch  # noqa: E402,F401
 
 from seabreeze_param_amd import hip, synth  # noqa: E402
@@ -272,7 +269,6 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
-    ap.add_argument("--no-fuse", action="store_true", help="measurement: k_scan and the strip kernel as two launches (sb_set_fuse(ctx, 0))")
     ap.add_argument("--static-sigma", action="store_true",
                     help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
     args = ap.parse_args()
@@ -284,6 +280,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if len(hip.hip_runtimes()) > 1:
+        raise SystemExit(f"bench.py: two HIP runtimes in this process ({hip.hip_runtimes()}): import torch before "
+                         "libseabreeze_hip.so is loaded -- refusing to time kernels torch's synchronisation cannot see")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.comm == "gloo":
@@ -315,10 +314,11 @@ def main():
     ctx = hip.Context(local_rank)
     runtimes = hip.hip_runtimes()
     shared_runtime = len(runtimes) == 1
+    if not shared_runtime:
+        raise SystemExit(f"bench.py: torch and libseabreeze_hip.so do not share one HIP runtime ({runtimes}): import torch before "
+                         "the library is loaded -- refusing to time kernels torch's synchronisation cannot see")
     if args.no_fold:
         ctx.set_fold(False)
-    if args.no_fuse:
-        ctx.set_fuse(False)
     if world > 1 and comm == "native":
         # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
         uid = [hip.comm_unique_id() if rank == 0 else None]
@@ -461,16 +461,7 @@ def main():
     n_local = nx * (r1 - r0)
     n_band_local = int(band[r0:r1].sum())
     ab = algorithmic_bytes(n_local, n_band_local, nz, s=esz, wind_final=(world == 1))
-    # k_scan's pass and the march in one launch (the default on one domain): the library reports the fused kernel's event
-    # time in the contrast kernel's slot and leaves k_scan's empty; its algorithmic bytes are the two kernels' together
-    fused = world == 1 and kern_ms["k_scan"] == 0.0 and kern_ms["k_thc"] > 0.0
-    if fused:
-        kern_ms["k_scan_strip"] = kern_ms.pop("k_thc")
-        kern_ms.pop("k_scan")
-        ab["k_scan_strip"] = ab["k_scan"] + ab["k_thc"]
-        if replan is not None:
-            replan["k_scan_strip"] = replan.pop("k_thc")
-    knames = ("k_scan_strip", "k_wind") if fused else ("k_scan", "k_wind", "k_thc")
+    knames = ("k_scan", "k_wind", "k_thc")
     dom = max(knames, key=lambda k: kern_ms[k])
     fracs = {k: (ab[k] / (kern_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms[k] > 0 else None) for k in knames}
     lim = min((k for k in knames if fracs[k] is not None), key=lambda k: fracs[k], default=None)
@@ -498,15 +489,14 @@ def main():
                         + (f"(BASELINE.json configs[{cfg_index}])" if cfg_index is not None else "(not a BASELINE.json configuration)"),
             "baseline_config_index": cfg_index,
             "hip_runtime": runtimes,
-            "stream": ("torch's current stream (torch and the library share one HIP runtime)" if shared_runtime else
-                       "the library context's own stream (two HIP runtimes in the process; timed regions close with both synchronisations)"),
+            "stream": "torch's current stream (torch and the library share one HIP runtime)",
             "plan_cache": "stored",
             "nx": nx, "ny": ny, "nz": nz,
             "band_fraction": n_band_total / (nx * ny),
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
             "variant": ("static-sigma (opt-in; not the reference's per-call statistics)" if args.static_sigma else "default")
-                       + (", k_prep as its own kernel" if args.no_fold else "") + (", k_scan and k_strip as two launches" if args.no_fuse else ""),
+                       + (", k_prep as its own kernel" if args.no_fold else ""),
             "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
             "multi_rank_rccl": "unmeasured on hardware so far (one GPU per box in the build pool)" if world == 1 else "this run",
             "input_gen_s": round(gen_s, 1),

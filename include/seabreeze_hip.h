@@ -94,11 +94,10 @@ int  sb_set_fold(sb_ctx *ctx, int on);
    difference makes the kernel plan afresh (on, the default).  Off: it plans every call.  A measurement and test
    knob: results never depend on it.                                                                       */
 int  sb_set_plan_cache(sb_ctx *ctx, int on);
-/* A whole single-domain host-model call on the strip kernel is TWO launches: k_scan's pass over sigma and mask and the
-   march in one kernel (k_scan_strip: the workgroups meet at a grid-wide barrier inside it, with the march's plan
-   already in LDS and its first loads under way), then k_wind (on, the default).  Off: k_scan and the strip kernel as
-   launches of their own, as in a band step.  A measurement and test knob: results never depend on it.            */
-int  sb_set_fuse(sb_ctx *ctx, int on);
+/* Search radii beyond 16 (radius hints of 17 .. 32): in single precision the 96-column marching-strip kernel answers
+   windows of up to 31 cells from LDS (on, the default); off: the tile kernel, as in double precision.  A measurement and
+   test knob: results agree to single-precision rounding of the window means.                                      */
+int  sb_set_wide_strip(sb_ctx *ctx, int on);
 /* A band step (sb_band_seabreeze_diag_*_dev, or a diag call with gathered moments in use) on the strip kernel runs
    k_scan and k_wind ahead of the join with the communication stream and lets the contrast kernel apply the update
    (0, the default), or k_scan | join | contrast kernel, k_wind -- the three kernels of a single-domain call, one

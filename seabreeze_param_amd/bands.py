@@ -132,11 +132,12 @@ class BandRunner:
 
     # -- streams -----------------------------------------------------------------------
     def _stream(self):
-        """torch's current stream when torch and the library share one HIP runtime (torch imported before the library
-        was loaded), else None: the library then runs on its context's own stream (hip.torch_stream_handle)."""
+        """torch's current stream: torch and the library share one HIP runtime (torch imported before the library was
+        loaded; hip.torch_stream_handle checks it once and refuses the other order)."""
         if self._shared_runtime is None:                # (reading the process's maps is not a per-step affair)
-            self._shared_runtime = len(_hip.hip_runtimes()) == 1
-        return self.torch.cuda.current_stream().cuda_stream if self._shared_runtime else None
+            _hip.torch_stream_handle(self.torch)
+            self._shared_runtime = True
+        return self.torch.cuda.current_stream().cuda_stream
 
     def synchronize(self):
         """Everything this runner enqueued has finished, whichever runtime and stream ran it."""

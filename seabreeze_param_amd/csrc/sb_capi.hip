@@ -104,9 +104,8 @@ class HostPool {
     bool quit_ = false;
 };
 
-// words of sb_ctx::ticket: [0] k_scan's spare word, [1] k_stats' / a band step's ticket, [2..7] the fused kernel's two
-// barrier words and fill counter (three per launch, alternating launches), [8] barrier waits that gave up
-enum { SB_TICKET_FUSE = 2, SB_TICKET_FUSE_ERR = 8, SB_TICKET_WORDS = 12 };
+// words of sb_ctx::ticket: [0] k_scan's spare word, [1] k_stats' / a band step's ticket
+enum { SB_TICKET_WORDS = 2 };
 
 struct DiagStream {
     bool active = false;
@@ -135,8 +134,7 @@ struct sb_ctx {
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
     int no_plan_cache = 0;              // sb_set_plan_cache(ctx, 0): the strip kernel plans its march afresh every call
-    int no_fuse = 0;                    // sb_set_fuse(ctx, 0): k_scan and the strip kernel as two launches
-    unsigned fuse_seq = 0;              // fused launches so far: their barrier words alternate
+    int no_wide_strip = 0;              // sb_set_wide_strip(ctx, 0): radii beyond 16 take the tile kernel in single precision too
     int band_late_wind = 0;             // sb_set_band_order(ctx, 1): a band step runs the contrast before k_wind (measurement)
     const void *stats_sigma = nullptr;
     int stats_dims[4] = {0, 0, 0, 0};   // nx, ny, halo, sizeof(T)
@@ -248,34 +246,38 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     // contrast kernel: marching strips (32 owned longitudes x 16-row blocks, flags strip-major with a virtual block
     // above and below every strip) for LDS halos up to 16 cells, LDS tiles (row-major flags) beyond
     int txw, tyrows, tx, ty;
-    const bool strip = H <= 16 && sb_strip_shape(g.nx, g.rows, &tx, &ty);
+    // (radii beyond 16: in single precision the 96-column strip kernel answers up to 31 from LDS -- what a distance field
+    // made with a window of up to 30 cells needs; double precision, and sb_set_wide_strip(ctx, 0), keep the tile kernel)
+    const bool strip32 = H > 16 && sizeof(T) == 4 && !c->no_wide_strip && sb_strip32_shape(g.nx, g.rows, &tx, &ty);
+    const bool strip = strip32 || (H <= 16 && sb_strip_shape(g.nx, g.rows, &tx, &ty));
+    const int vb = strip32 ? 2 : 1;                  // virtual blocks above and below every strip in the flags
     if (strip) { txw = 32; tyrows = 16; }
     else {
         sb_thc_tile_shape(H > 16 ? H : 24, &txw, &tyrows);
         tx = (g.nx + txw - 1) / txw; ty = (g.rows + tyrows - 1) / tyrows;
     }
-    const int Hk = strip ? 16 : (H > 16 ? H : 24);   // halo of the kernel that runs
+    const int Hk = strip32 ? 32 : strip ? 16 : (H > 16 ? H : 24);   // halo of the kernel that runs
     // Two buffers of [per-tile flags | 2 slow-path counters], used by alternate calls: k_scan
     // raises flags in this call's buffer, k_wind clears the other one for the next call, so no
     // memset sits on the critical path and the last call's values stay readable.
-    const int ntile = strip ? tx * (ty + 2) : tx * ty;
+    const int ntile = strip ? tx * (ty + 2 * vb) : tx * ty;
     const int nflag = ntile + 2;
-    if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag || c->tiles_strip != (strip ? 1 : 0)) {
+    if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag || c->tiles_strip != (strip ? vb : 0)) {
         if ((rc = ensure(c, c->tiles, (size_t)2 * nflag * sizeof(int)))) return rc;
         // (in stream order: a plain hipMemset runs on the null stream, which the non-blocking streams kernels are
         // enqueued on do not wait for -- a late memset could wipe flags k_scan had already raised)
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int), st));
         c->tiles_n = nflag;
-        c->tiles_strip = strip ? 1 : 0;
+        c->tiles_strip = strip ? vb : 0;
         c->flag_parity = 0;
     }
     int *flags_now = (int *)c->tiles.p + (size_t)c->flag_parity * nflag;
     int *flags_next = (int *)c->tiles.p + (size_t)(1 - c->flag_parity) * nflag;
     job.thc_ty = tyrows; job.thc_ntx = tx; job.thc_nty = ty;
     job.thc_txs = txw == 32 ? 5 : 6;
-    job.strip = strip ? 1 : 0;
-    if (strip) { job.tile_sx = ty + 2; job.tile_sy = 1; job.tile_off = 1; }
+    job.strip = strip32 ? 2 : strip ? 1 : 0;
+    if (strip) { job.tile_sx = ty + 2 * vb; job.tile_sy = 1; job.tile_off = vb; }
     else { job.tile_sx = 1; job.tile_sy = tx; job.tile_off = 0; }
     job.bandbits = (uint64_t *)c->bandbits.p;
     job.clsbits = (uint64_t *)c->clsbits.p;
@@ -341,7 +343,7 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
                 c->plan_bits = nullptr;
             }
             ++c->call_seq;
-            const int key[8] = {g.nx, g.ny, g.h, g.bnd, g.rows, c->ncu, tx, ty};
+            const int key[8] = {g.nx, g.ny, g.h, g.bnd, g.rows, c->ncu, tx, ty | (vb << 24)};     // (the two strip kernels' plans differ)
             c->plan_use = c->plan_bits == c->bandbits.p && std::memcmp(key, c->plan_key, sizeof(key)) == 0 ? 1 : 0;
             std::memcpy(c->plan_key, key, sizeof(key));
             c->plan_bits = c->bandbits.p;
@@ -380,13 +382,6 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.gath = nullptr; job.ngath = 0;
     int launched = 0;
     lc.launches = &launched;
-    // k_scan's pass and the march in one launch: whole single-domain host-model calls on the strip kernel, every
-    // workgroup of the grid on a compute unit of its own (they meet at a barrier inside the kernel)
-    lc.fuse = !c->no_fuse && phases == 3 && !c->gathered && strip_folds && job.wind_final && c->ncu <= c->ncu_dev && c->ncu <= 1024;
-    lc.fuse_ticket = c->ticket + SB_TICKET_FUSE + 3 * (c->fuse_seq & 1u);
-    lc.fuse_ticket_next = c->ticket + SB_TICKET_FUSE + 3 * ((c->fuse_seq + 1u) & 1u);
-    lc.fuse_err = c->ticket + SB_TICKET_FUSE_ERR;
-    if (lc.fuse) ++c->fuse_seq;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
     {
         const hipError_t le = sb_launch_diag<T>(job, Hk, lc);
@@ -1624,9 +1619,10 @@ int sb_set_plan_cache(sb_ctx *c, int on) {
     return SB_OK;
 }
 
-int sb_set_fuse(sb_ctx *c, int on) {
+int sb_set_wide_strip(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    c->no_fuse = on ? 0 : 1;
+    c->no_wide_strip = on ? 0 : 1;
+    c->plan_bits = nullptr;
     return SB_OK;
 }
 

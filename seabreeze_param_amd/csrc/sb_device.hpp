@@ -271,7 +271,8 @@ struct DiagJob {
     int tile_sx, tile_sy, tile_off; // flag of tile (column tx, row ty) = tile_nnmax[tx * tile_sx + ty * tile_sy + tile_off]:
                                     //   row-major for the tile kernel; strip-major with a virtual block above and below
                                     //   every strip for the strip kernel (sb_strip_kernel.hip)
-    int strip;                      // 1: the strip kernel runs the contrast (LDS halo <= 16)
+    int strip;                      // 1: the strip kernel runs the contrast (LDS halo <= 16); 2: the 96-column strip kernel (radii
+                                    //    up to 31, single precision: sb_strip32_kernel.hip)
     // the strip kernel's plan (its share of the blocks, the order of its steps, the band cells of every block it
     // queries) depends on the band plane alone; it is kept from call to call and remade when k_scan finds that the
     // plane changed -- see sb_strip_kernel.hip

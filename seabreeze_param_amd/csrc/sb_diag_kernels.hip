@@ -172,7 +172,7 @@ template <typename T, int SPT, bool WR, bool ST>      // WR: f2py flavour; ST: a
 __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__restrict__ partials) {
     constexpr bool do_stats = ST;
     Moments t;
-    const bool plane_changed = sb_scan_pass<T, SPT, WR, ST, true>(job, t);
+    const bool plane_changed = sb_scan_pass<T, SPT, WR, ST>(job, t);
     const Geo g = job.g;
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     if (plane_changed && job.plan_gen) atomicMax(job.plan_gen, job.call_id);
@@ -582,9 +582,10 @@ static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
 #define SB_EV_BEGIN(k) do { if (ev) { (void)hipEventRecord(ev[2 * (k)], st); *lc.prof_mask |= 1u << (k); } } while (0)
 #define SB_EV_END(k)   do { if (ev) (void)hipEventRecord(ev[2 * (k) + 1], st); } while (0)
 
-// the contrast kernel for this job: marching strips (LDS halo 16) or LDS tiles (halos of 24 and 32 cells)
+// the contrast kernel for this job: marching strips (LDS halo 16; 32 in single precision) or LDS tiles (halos of 24 and 32 cells)
 template <typename T>
 static hipError_t launch_contrast(const DiagJob<T> &job, int H, int ncu, hipStream_t st) {
+    if (job.strip == 2) return sb_launch_strip32<T>(job, ncu, st);
     return job.strip ? sb_launch_strip<T>(job, ncu, st) : sb_launch_thc<T>(job, H, ncu, st);
 }
 
@@ -608,22 +609,6 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     // Single-domain calls run the contrast first and let k_wind apply the thresholds and the state update
     // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there the contrast
     // kernel applies them.
-    if (job.wind_final && ph1 && ph2 && !gathered && lc.fuse && job.strip && job.t0_fly && !lc.no_fold && job.flavour == SB_FLAVOUR_GENERIC) {
-        // ---- two launches: k_scan's pass + the march (k_scan_strip), k_wind ----
-        DiagJob<T> fj = job;
-        fj.fold = 1;
-        fj.fold_partials = lc.partials;
-        fj.fold_nparts = reuse ? 0 : lc.ncu;             // (every workgroup of the fused grid scans, and hands over a partial)
-        fj.stats_out = (T *)lc.stats;
-        SB_EV_BEGIN(SB_PROF_THC);                        // (reported as the contrast kernel's time; k_scan's slot stays empty)
-        if ((e = sb_launch_scan_strip<T>(fj, lc.ncu, !reuse, lc.partials, lc.fuse_ticket, lc.fuse_ticket_next, lc.fuse_err, st)) != hipSuccess) return e;
-        SB_EV_END(SB_PROF_THC);
-        SB_EV_BEGIN(SB_PROF_WIND);
-        launch_wind<T>(job, lc.ncu, st);
-        SB_EV_END(SB_PROF_WIND);
-        if (lc.launches) *lc.launches += 2;
-        return hipGetLastError();
-    }
     if (job.wind_final && ph1 && ph2 && !gathered) {
         SB_EV_BEGIN(SB_PROF_SCAN);
         launch_scan<T>(job, nblk, lc.partials, !reuse, st);

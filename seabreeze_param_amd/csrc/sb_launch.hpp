@@ -37,10 +37,6 @@ struct SbLaunchCtx {
     bool segs_stand;                // band step on the strip kernel: the segment lists of the call before are in place
                                     // (same geometry; k_wind checks on the device that the planes did not change): no k_prep
     int *launches;                  // += kernels enqueued by the call, or nullptr
-    bool fuse;                      // single-domain host-model call on the strip kernel: k_scan's pass and the march in one launch
-    unsigned *fuse_ticket;          // ... its barrier words: [2 of this launch | 2 of the next], alternating (see FusedSync) ...
-    unsigned *fuse_ticket_next;
-    unsigned *fuse_err;             // ... and the word that counts barrier waits that gave up
 };
 
 template <typename T>
@@ -60,12 +56,17 @@ hipError_t sb_launch_thc(const DiagJob<T> &job, int H, int ncu, hipStream_t st);
 // the marching-strip contrast kernel (sb_strip_kernel.hip): LDS halo of 16 cells, ranks k_scan's flags itself
 template <typename T>
 hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st);
-// k_scan's pass and the march in one launch (k_scan_strip): single-domain host-model calls on the strip kernel
-template <typename T>
-hipError_t sb_launch_scan_strip(const DiagJob<T> &job, int ncu, bool scan_stats, Moments *partials, unsigned *ticket_now,
-                                unsigned *ticket_next, unsigned *err, hipStream_t st);
 // its block grid (strips x 16-row blocks) for nx x rows interior cells; false: the grid is too large for it
 bool sb_strip_shape(int nx, int rows, int *ntx, int *nty);
+// the marching-strip kernel for search radii up to 31 (sb_strip32_kernel.hip): single precision only (hipErrorInvalidValue
+// for double); its flags carry TWO virtual blocks above and below every strip
+template <typename T>
+hipError_t sb_launch_strip32(const DiagJob<T> &job, int ncu, hipStream_t st);
+template <>
+hipError_t sb_launch_strip32<float>(const DiagJob<float> &job, int ncu, hipStream_t st);
+template <>
+hipError_t sb_launch_strip32<double>(const DiagJob<double> &job, int ncu, hipStream_t st);
+bool sb_strip32_shape(int nx, int rows, int *ntx, int *nty);
 
 // theta <- theta - (gmma*z)*sigmoid(sigma) over n cells, with the scalars the last diag call left in `stats`
 template <typename T>

@@ -1,5 +1,6 @@
-// sb_scan_body.hpp -- the one pass over sigma and mask (k_scan's body), shared by k_scan (sb_diag_kernels.hip) and the
-// fused scan + strip kernel (sb_strip_kernel.hip).
+// sb_scan_body.hpp -- the one pass over sigma and mask: k_scan's loop (sb_diag_kernels.hip), kept apart from the kernel's
+// hand-over code (round 4 built a kernel that ran this pass and the strip kernel's march in one launch; it measured
+// slower than two launches and was removed: profiles/r04_fused_scan_strip_ab.txt).
 //   * sigma  -> shifted sums about its first interior value -> one (count, s1, s2, min, max) partial per workgroup
 //   * mask   -> land-side bit  mask >= 0              ref: generic/sea_breeze_diag.f90:182,200
 //            -> band bit  !(|mask| > maxdist)         ref :174
@@ -11,10 +12,9 @@
 #define SB_EAGER_PLANES 0          // 1: every word of the planes is written every call (A/B, debugging)
 #endif
 
-// WR: f2py flavour; ST: accumulate sigma's moments; FILL: write the fill value outside the band (the fused kernel of
-// sb_strip_kernel.hip leaves that to the tail of its march).  Returns this THREAD's shifted sums in `mine` and whether
-// this thread's wave saw a word of the planes change.  AF: the block flags are raised by atomics (see there).
-template <typename T, int SPT, bool WR, bool ST, bool FILL, bool AF = false>
+// WR: f2py flavour; ST: accumulate sigma's moments.  Returns this THREAD's shifted sums in `mine` and whether this
+// thread's wave saw a word of the planes change.
+template <typename T, int SPT, bool WR, bool ST>
 __device__ __forceinline__ bool sb_scan_pass(const DiagJob<T> &job, Moments &mine, unsigned kernarg_job_off = 0) {
     constexpr bool wrapper = WR, do_stats = ST;
     constexpr int SCAN_NT = SB_STATS_NT;
@@ -123,16 +123,10 @@ __device__ __forceinline__ bool sb_scan_pass(const DiagJob<T> &job, Moments &min
                 hi = hi > 64 ? 64 : hi;
                 if (lane <= (64 >> txs) && lo < hi) {
                     const uint64_t m = (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
-                    if (wb & m) {
-                        int *flag = &job.tile_nnmax[(tA + lane) * job.tile_sx + (yi / job.thc_ty) * job.tile_sy + job.tile_off];
-                        // (fused kernel: the march of another compute unit may be leaving a block's largest radius in the same
-                        // word meanwhile -- both sides by device-scope atomics, which meet at one place)
-                        if (AF) __hip_atomic_fetch_max(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else *flag = 1;                      // benign duplicates
-                    }
+                    if (wb & m) job.tile_nnmax[(tA + lane) * job.tile_sx + (yi / job.thc_ty) * job.tile_sy + job.tile_off] = 1;   // benign duplicates
                 }
             }
-            if (FILL && interior && yi < g.rows && !band) {
+            if (interior && yi < g.rows && !band) {
                 const unsigned o = (unsigned)yi * unx + (unsigned)xi;
                 if (!wrapper) job.sb_con[o] = job.fill;
                 else {

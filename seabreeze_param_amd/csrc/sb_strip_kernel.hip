@@ -36,7 +36,7 @@
 // memory and used again for as long as k_scan finds the band and land-side planes unchanged (see `cached` below).
 // DESIGN.md section 2.4 has the measurements behind the choices, and what hipcc does with loads kept in flight.
 #include "sb_thc_common.hpp"
-#include "sb_scan_body.hpp"
+#include "sb_strip_common.hpp"
 
 #define STRIP_H 16                // halo of the tables = largest radius answered from LDS
 #define STRIP_W 64                // staged columns = lanes
@@ -52,7 +52,6 @@
 #define STRIP_FB 40               // fractional bits of the fixed-point t0
 #define STRIP_DEPTH 3             // blocks of inputs in flight per wave
 
-typedef unsigned long long u64;
 
 // Diagnostic build (-DSB_STAMPS: `make stamps`, tools/stamp_strip.py): every wave leaves the 100 MHz wall clock at a few
 // marks -- one scalar clock read and one exec-masked store each, no registers held (an earlier version summed shader
@@ -126,56 +125,6 @@ __device__ __forceinline__ u64 sb_to_fixed(double x, sb_cdp k) {
     return (u64)__double_as_longlong(__builtin_fma(x, SB_K(16, 0x1p40), SB_K(17, 0x1.8p52)));
 }
 
-// inclusive prefix sums over the 64 lanes of a wave of two 64-bit integers at once: per step and value one
-// v_add_co_u32 + one v_addc_co_u32, the lane shift fused into the add (DPP).  The two chains alternate, so a value
-// written by one step is read by the next four instructions later (a DPP read needs two wait states after a VALU
-// write; hipcc pads nothing inside an asm statement -- hence also the leading s_nop).  Needs all 64 lanes active.
-__device__ __forceinline__ void sb_scan2_u64(u64 &a, u64 &b) {
-    unsigned al = (unsigned)a, ah = (unsigned)(a >> 32), bl = (unsigned)b, bh = (unsigned)(b >> 32);
-#define SB_SCAN_STEP(ctl)                                          \
-    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctl "\n\t"               \
-    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctl "\n\t"         \
-    "v_add_co_u32_dpp %2, vcc, %2, %2 " ctl "\n\t"               \
-    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctl "\n\t"
-    asm volatile("s_nop 1\n\t"
-                 SB_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 SB_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 "s_nop 0"
-                 : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh)::"vcc");
-#undef SB_SCAN_STEP
-    a = ((u64)ah << 32) | al;
-    b = ((u64)bh << 32) | bl;
-}
-
-// ... of one 64-bit integer (rows that lie on one side of the coast: the land-side sums are all zero, or equal the
-// sums over all cells); the steps follow each other directly, so each is padded to the two wait states of a DPP read
-__device__ __forceinline__ void sb_scan1_u64(u64 &a) {
-    unsigned al = (unsigned)a, ah = (unsigned)(a >> 32);
-#define SB_SCAN_STEP1(ctl)                                         \
-    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctl "\n\t"               \
-    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctl "\n\ts_nop 0\n\t"
-    asm volatile("s_nop 1\n\t"
-                 SB_SCAN_STEP1("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP1("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP1("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP1("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                 SB_SCAN_STEP1("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 SB_SCAN_STEP1("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 : "+v"(al), "+v"(ah)::"vcc");
-#undef SB_SCAN_STEP1
-    a = ((u64)ah << 32) | al;
-}
-
-__device__ __forceinline__ u64 sb_uniform64(u64 v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
-
 // what a lane holds of one staged row between the issue of its loads and S1
 template <typename T, bool FLY>
 struct StripRegs {
@@ -185,145 +134,36 @@ struct StripRegs {
     uint32_t lbit;                 // the cell's bit in lw; 0: no such cell
 };
 
-// schedule entry of a step: position | flags
-#define SCH_Q2 (1u << 16)          // the block two positions up is active: its band cells are queried in this step's S2
-#define SCH_RESTART (1u << 17)     // the block before is not staged: the tables start afresh here
-#define SCH_DRAIN (1u << 18)       // no block: the step behind the last block of a run, in which ...
-#define SCH_Q1 (1u << 19)          // ... the block one position up (the run's last active one) is queried
-#define SCH_IDLE (1u << 20)        // nothing but the loads of the block three steps on (warm-up and padding steps)
-#define SCH_QI_SHIFT 22            // bits 22 .. 27: number of the step's cell list in the stored plan
-
-typedef const __attribute__((address_space(4))) u64 *cu64p;          // read-only planes: scalar loads
-
-// A cell whose window outgrows the tables (none on a grid whose distance field was made with a window of at most 15
-// cells) is marked during the march -- a NaN of this payload in thc -- and handled after it, by the one copy of the
-// global-memory search that the kernel holds (three inlined copies inside the march's loop tripled the code there, and
-// a call would have the compiler wait for the prefetched blocks around it).
-template <typename T> __device__ __forceinline__ T strip_mark();
-template <> __device__ __forceinline__ double strip_mark<double>() { return __longlong_as_double(0x7ff85ea5b4ee2e00ll); }
-template <> __device__ __forceinline__ float strip_mark<float>() { return __uint_as_float(0x7fc5ea5bu); }
-__device__ __forceinline__ bool strip_is_mark(double v) { return __double_as_longlong(v) == 0x7ff85ea5b4ee2e00ll; }
-__device__ __forceinline__ bool strip_is_mark(float v) { return __float_as_uint(v) == 0x7fc5ea5bu; }
-
-#ifndef SB_TRUST_LISTS
-#define SB_TRUST_LISTS 1             // 0: k_wind's segment lists are compacted in every call (A/B, debugging)
-#endif
-#ifndef SB_FUSE_FILL_IN_SCAN
-#define SB_FUSE_FILL_IN_SCAN 0    // 1: the fused kernel's scan pass writes the fill value itself, as k_scan does (A/B)
-#endif
-
-// The LDS of one workgroup: all of it (160 KB).  One object per kernel, handed to the march by reference -- the fused
-// kernel holds two instances of the march, which must share it.
-template <typename T>
-struct StripLds {
-    u64 sA[STRIP_RING * STRIP_P];
-    u64 sL[STRIP_RING * STRIP_P];
-    u64 s_land[STRIP_RING];
-    u64 s_bits[STRIP_MAXW];
-    uint2 s_ent[STRIP_SCHED];
-    Moments s_wpart[STRIP_NT / SB_WAVE];
-    T s_sdr[2];
-    int s_scan[STRIP_NT / SB_WAVE];
-    int s_misc[12];
-    unsigned short sC[STRIP_RING * STRIP_P];
-    unsigned short s_cell[3][STRIP_SW * STRIP_C];
-};
-static_assert(sizeof(StripLds<double>) <= 160 * 1024 && sizeof(StripLds<float>) <= 160 * 1024, "k_strip: LDS of one workgroup");
-
-// The grid-wide hand-over of the fused kernel (k_scan_strip below): one word per barrier, zero when the launch begins
-// (every launch zeroes the words of the NEXT one, which alternate).  Arrivals count in the low 16 bits of the first
-// word, workgroups WITHOUT a usable stored plan in the bits above.
-struct FusedSync {
-    unsigned *ticket;               // [0] first barrier, [1] second barrier (taken only when the plan does not stand),
-                                    // [2] the fill's chunk counter
-    unsigned *err;                  // += 1 when a wait gave up (2 s: something is badly wrong; the kernel still ends)
-    Moments *partials;              // the workgroups' shifted sums, handed over write-through
-};
-
-// The fill value outside the coastal band (ref: generic/sea_breeze_diag.f90:174-176), left out of the fused kernel's scan
-// pass -- which then only reads -- and written BEHIND the march: the workgroups' shares of the march differ in length
-// (18 .. 29 us around 24 on the headline grid), and whoever is done draws chunks of 256 segments from one counter until
-// none is left.  The band bits of a segment are those k_scan's pass of this launch left (or found in place).
-#define FILL_CHUNK 256
-template <typename T>
-__device__ __forceinline__ void sb_fill_tail(const DiagJob<T> &job, unsigned *ctr, int *s_slot) {
-    const Geo g = job.g;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
-    const unsigned nchunk = (nseg + FILL_CHUNK - 1) / FILL_CHUNK;
-    const unsigned unw = (unsigned)g.nw;
-    unsigned nxt = 0;
-    if (tid == 0) nxt = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        __syncthreads();                                 // (the slot is free)
-        if (tid == 0) *s_slot = (int)nxt;
-        __syncthreads();
-        const unsigned cur = (unsigned)*s_slot;
-        if (cur >= nchunk) break;                        // (uniform)
-        if (tid == 0) nxt = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // travels under this chunk's stores
-        constexpr int PER = FILL_CHUNK / (STRIP_NT / SB_WAVE);       // segments per wave: consecutive ones
-        const unsigned s0 = cur * FILL_CHUNK + (unsigned)wv * PER;
-        uint64_t w[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) w[q] = job.bandbits[s0 + q < nseg ? s0 + q : 0u];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const unsigned seg = s0 + q;
-            if (seg >= nseg) break;
-            const unsigned Y = seg / unw, Xw = seg - Y * unw;
-            const int xi = (int)(Xw * 64u) + lane - g.h, yi = (int)Y - g.h;
-            const bool interior = xi >= 0 && xi < g.nx && yi >= 0 && yi < g.rows;
-            if (interior && !((w[q] >> lane) & 1ull)) job.sb_con[(unsigned)yi * (unsigned)g.nx + (unsigned)xi] = job.fill;
-        }
-    }
-}
-
-__device__ __forceinline__ bool sb_grid_wait(unsigned *word, unsigned n, unsigned *err, unsigned &seen) {
-    const long long t0 = wall_clock64();
-    for (;;) {
-        seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((seen & 0xffffu) >= n) return true;
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 200000000ll) {          // 100 MHz: two seconds
-            __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-}
-
-// The march of one workgroup.  FLY: t0 from theta, z, sigma while staging.  The contrast goes to thc; thresholds and
-// state update are k_wind's (a cell's winds and state loaded here, next to the prefetched blocks of the march, would
-// drain them at every step).
-// CO ("cached only"): the instance that marches by the stored plan and holds nothing else -- no planning, no count
-// table, no cell lists built.  FUSED (with CO): the instance behind the scan pass in k_scan_strip -- the workgroups meet
-// at a grid-wide barrier AFTER the plan's steps are in LDS and the first three blocks' loads are under way, and learn
-// there whether every workgroup's stored plan stands; if not, nothing has been written and the function returns false.
-// pg_known: the value of *plan_gen where the caller has read it past the caches (fused kernel), else -1.
-template <typename T, bool FLY, bool CO, bool FUSED>
-__device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, const Moments *fold_partials, int G, const StripJob<T> &job,
-                                            const DiagJob<T> &cold, const FusedSync &fs, const Moments &mine, int pg_known,
-                                            StripLds<T> &L) {
-    static_assert(!FUSED || (CO && FLY), "the fused instance marches by the stored plan");
+// FLY: t0 from theta, z, sigma while staging.  The contrast goes to thc; thresholds and state update are k_wind's (a
+// cell's winds and state loaded here, next to the prefetched blocks of the march, would drain them at every step).
+template <typename T, bool FLY>
+__global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_gen, const Moments *fold_partials, int G, StripJob<T> job) {
+    // (the three pointers the first loads of the kernel hang on come as leading arguments: with
+    // -amdgpu-kernarg-preload-count=7 they are in scalar registers when the wave starts, and the plan header, the
+    // change counter and k_scan's partial sums are requested without waiting for a load of the argument block)
     constexpr int H = STRIP_H, W = STRIP_W, SW = STRIP_SW, C = STRIP_C, P = STRIP_P, NWV = STRIP_NT / SB_WAVE;
     constexpr int RM = STRIP_RING - 1;
     static_assert(NWV == C && SW == 32, "one staged row per wave, 32 owned columns");
     static_assert(STRIP_SCHED == SB_PLAN_SCHED, "a stored plan holds one round's steps");
-    u64 (&sA)[STRIP_RING * STRIP_P] = L.sA;            // prefix sums of t0 (fixed point), every cell
-    u64 (&sL)[STRIP_RING * STRIP_P] = L.sL;            // ... land-side cells
-    unsigned short (&sC)[STRIP_RING * STRIP_P] = L.sC; // ... land-side count (modulo 2^16: a window holds < 2^16 cells)
-    u64 (&s_land)[STRIP_RING] = L.s_land;              // land-side bits of every ring row
-    u64 (&s_bits)[STRIP_MAXW] = L.s_bits;              // the active blocks as a bit plane
-    uint2 (&s_ent)[STRIP_SCHED] = L.s_ent;             // steps of the round: x = position | flags, y = strip << 16 | block
+    __shared__ u64 sA[STRIP_RING * P];                 // prefix sums of t0 (fixed point), every cell
+    __shared__ u64 sL[STRIP_RING * P];                 // ... land-side cells
+    __shared__ unsigned short sC[STRIP_RING * P];      // ... land-side count (modulo 2^16: a window holds < 2^16 cells)
+    __shared__ u64 s_land[STRIP_RING];                 // land-side bits of every ring row
+    __shared__ u64 s_bits[STRIP_MAXW];                 // the active blocks as a bit plane
+    __shared__ uint2 s_ent[STRIP_SCHED];               // steps of the round: x = position | flags, y = strip << 16 | block
                                                        // within the padded strip
-    unsigned short (&s_cell)[3][STRIP_SW * STRIP_C] = L.s_cell;   // the band cells of the block a step queries, compacted (three steps in flight)
-    Moments (&s_wpart)[STRIP_NT / SB_WAVE] = L.s_wpart;
-    int (&s_scan)[STRIP_NT / SB_WAVE] = L.s_scan;
-    int (&s_misc)[12] = L.s_misc;                      // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked,
+    __shared__ unsigned short s_cell[3][SW * C];       // the band cells of the block a step queries, compacted (three steps in flight)
+    __shared__ Moments s_wpart[NWV];
+    __shared__ int s_scan[NWV];
+    __shared__ int s_misc[12];                         // [0] steps of the round, [1..3] entries of the three cell lists, [4] a cell was marked,
                                                        // [5], [6] the share (ranks of active blocks), [7] totals of the plane,
                                                        // [8] the plan of this call is stored (incl. its cell lists),
-                                                       // [9] query steps of the plan (a band step's update),
-                                                       // [10] fused kernel: every workgroup's stored plan stands, [11] its change counter
-    T (&s_sdr)[2] = L.s_sdr;
+                                                       // [9] query steps of the plan (a band step's update)
+    __shared__ T s_sdr[2];
+    static_assert(sizeof(u64) * (2 * STRIP_RING * P + STRIP_RING + STRIP_MAXW) + 2 * STRIP_RING * P + 8 * STRIP_SCHED +
+                          6 * SW * C + sizeof(Moments) * NWV + 4 * NWV + 48 + 16 <= 160 * 1024,
+                  "k_strip: LDS of one workgroup");
+
     const Geo g = job.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,7 +178,7 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
     double shift_c = 0.0;
     const bool fold_stats = job.fold && job.fold_nparts > 0;
     if (fold_stats) {
-        if (!FUSED) { if (tid < job.fold_nparts) pm = fold_partials[tid]; }     // (fused: behind the grid barrier, past the caches)
+        if (tid < job.fold_nparts) pm = fold_partials[tid];
         shift_c = (double)job.sigma[(size_t)g.h * g.nxh + g.h];
     } else if (FLY && job.ngath > 0) {
         // band step: the first wave merges the moments gathered from all ranks in rank order (one tree on every
@@ -367,30 +207,7 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
     unsigned *const plan_lists = (unsigned *)(plan_wg + SB_PLAN_LIST_OFF);
     const int plan_stored = ((cintp)plan_wg)[0], plan_nst = min(((cintp)plan_wg)[1], STRIP_SCHED);
     const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
-    // (uniform.  The fused instance SPECULATES that the plan stands -- k_scan's pass of this very launch may still be
-    // running on other compute units -- and is told at the grid barrier; it reads the change counter past the caches)
-    const int pg_seen = FUSED ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(plan_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                              : (pg_known >= 0 ? pg_known : *(cintp)plan_gen);
-    const bool plan_ok = job.plan_use != 0 && plan_stored != 0 && pg_seen <= plan_stored;
-    if (FUSED) {
-        // arrive: this workgroup's shifted sums (write-through, drained), then the ticket
-        if (tid == 0) {
-            if (fold_stats) {
-                double *dst = (double *)&fs.partials[blockIdx.x];
-                const double v[5] = {mine.n, mine.mean, mine.m2, mine.mn, mine.mx};
-                for (int i = 0; i < 5; ++i) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(fs.ticket, 1u + (plan_ok ? 0u : 0x10000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!plan_ok) {                                  // (uniform) no plan to march by: everybody will be sent round
-            if (tid == 0) { unsigned seen; (void)sb_grid_wait(fs.ticket, (unsigned)G, fs.err, seen); }
-            __syncthreads();
-            return false;
-        }
-    }
-    const bool cached = CO ? true : plan_ok;
-    if (CO && !FUSED && !plan_ok) return false;          // (callers of the plain CO instance check first; nothing written)
+    const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)plan_gen <= plan_stored;      // uniform
     auto load_plane = [&]() {
         u64 mine = 0;
         for (int base = 0; base < nch; base += 8) {              // 8 loads in flight (clamped, so none is conditional)
@@ -419,7 +236,7 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
     // the zero column of the three tables (never written again) while the flags travel
     for (int i = tid; i < STRIP_RING; i += STRIP_NT) { sA[i * P] = 0; sL[i * P] = 0; sC[i * P] = 0; }
     if (tid == 0) s_misc[4] = 0;
-    if (fold_stats && !FUSED) wave_total_shifted_store(pm, s_wpart);
+    if (fold_stats) wave_total_shifted_store(pm, s_wpart);
     SB_T(1);                                             // first barrier reached
     __syncthreads();
     SB_T(2);                                             // ... passed
@@ -536,15 +353,18 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
                 win |= (in && ((w >> (q & 63)) & 1ull)) ? 1u << d : 0u;
             }
             const bool st = pp <= p1 + 1 && (win & 0xeu) != 0u;                   // pp - 1, pp, pp + 1
-            const bool st_prev = (win & 0x7u) != 0u, st_next = (win & 0x1cu) != 0u;
+            // (a run never crosses from one strip into the next: the virtual block below a strip ends it, the one above the
+            // next strip starts afresh -- the blocks of a run are queried by their position within ONE strip; found in
+            // round 4 on a grid whose band reaches the first and the last row)
+            const int sp = (int)__umulhi((unsigned)(pp < 0 ? 0 : pp), npad_magic), jpp = pp - sp * npad;
+            const bool st_prev = (win & 0x7u) != 0u && jpp != 0, st_next = (win & 0x1cu) != 0u && jpp != npad - 1;
             const bool en = st && !st_next;
             const u64 ms = __builtin_amdgcn_ballot_w64(st), me = __builtin_amdgcn_ballot_w64(en);
             const u64 below = (1ull << lane) - 1ull;
             const int at = n_out + __popcll(ms & below) + __popcll(me & below);
             n_out += __popcll(ms) + __popcll(me);
             if (st) {
-                const int sp = (int)__umulhi((unsigned)pp, npad_magic);
-                const unsigned sjv = ((unsigned)sp << 16) | (unsigned)(pp - sp * npad);
+                const unsigned sjv = ((unsigned)sp << 16) | (unsigned)jpp;
                 const unsigned e = (unsigned)pp | ((win & 1u) ? SCH_Q2 : 0u) | (st_prev ? 0u : SCH_RESTART);
                 if (at < STRIP_SCHED) s_ent[at] = make_uint2(e, sjv);
                 if (en && at + 1 < STRIP_SCHED) s_ent[at + 1] = make_uint2((unsigned)pp | SCH_DRAIN | ((win & 2u) ? SCH_Q1 : 0u), sjv);
@@ -896,48 +716,14 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
             }
         }
     };
-    // ---- the fused instance's grid barrier: k_scan's pass has ended on every compute unit.  Behind it: does every
-    // workgroup's stored plan stand (no plane word changed in this launch, nobody arrived without a plan)?  If so the
-    // partial sums of sigma are fetched past the caches; if not, the caller sends everybody round the long way.
-    // Returns with the wave totals of the partial sums in s_wpart and a workgroup barrier passed.
-    bool synced = false;
-    auto grid_sync = [&]() __attribute__((always_inline)) -> bool {
-        if (tid == 0) {
-            unsigned seen = 0;
-            const bool came = sb_grid_wait(fs.ticket, (unsigned)G, fs.err, seen);
-            const int pg = __hip_atomic_load(plan_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_misc[10] = (came && (seen >> 16) == 0u && pg < job.call_id) ? 1 : 0;
-        }
-        __syncthreads();
-        if (s_misc[10] == 0) return false;
-        if (fold_stats) {
-            if (tid < job.fold_nparts) {
-                const double *src = (const double *)&fs.partials[tid];
-                pm.n = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pm.mean = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pm.m2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pm.mn = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pm.mx = __hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            wave_total_shifted_store(pm, s_wpart);
-            __syncthreads();
-        }
-        return true;
-    };
-    if (FUSED && r_begin >= r_end) {                     // (no share of the march: the barrier all the same)
-        if (!grid_sync()) return false;
-        synced = true;
-    }
     if (fold_stats && r_begin >= r_end && blockIdx.x == 0) finish_stats();
     // ---- rounds: at most STRIP_ROUND active blocks each (one round on every grid the plane holds with >= 256 workgroups) ----
-    // (a stored plan holds exactly one round: the instance that marches by it carries no planning code)
-    for (int ra = r_begin; ra < r_end; ra += CO ? 0x40000000 : STRIP_ROUND) {
-        if (!CO && ra > r_begin) {                       // (a further round: wave 0 plans it; the cell lists lay over the prefix array)
+    for (int ra = r_begin; ra < r_end; ra += STRIP_ROUND) {
+        if (ra > r_begin) {                              // (a further round: wave 0 plans it; the cell lists lay over the prefix array)
             if (wv == 0) { make_prefix(false); make_schedule(ra, min(ra + STRIP_ROUND, r_end)); }
             __syncthreads();
         }
         const int nst = __builtin_amdgcn_readfirstlane(s_misc[0]);
-        if (FUSED && !synced && nst == 0) { if (!grid_sync()) return false; synced = true; }
         if (nst == 0) break;
         // a step's entry travels in scalar registers from the step that issues its block's loads (three steps ahead)
         // to the step itself; behind the end of the schedule: idle steps
@@ -957,9 +743,6 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
         SB_T(30);
         issue(R1, J1); issue(R2, J2);
         SB_T(31);
-        // (fused: the barrier stands HERE -- the steps are in LDS, the first three blocks' loads travel while the last
-        // compute units finish their share of k_scan's pass)
-        if (FUSED && !synced) { if (!grid_sync()) return false; synced = true; }
         if (fold_stats && ra == r_begin) finish_stats();
         SB_T(4);                                         // march begins
         // A step: S1 of block i (and the list of the band cells to query), barrier, S2 (sums along latitude || queries
@@ -1026,9 +809,9 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
         job.thc[o] = mulg * cg;
     };
     if (s_misc[4] != 0 && cached) {                      // (uniform: read behind the round's last barrier)
-        // A stored plan knows its marked cells: the entries of its lists whose radius field is zero.  (Not by way of the
-        // block flags, as below: in the fused kernel those are being raised by other compute units in this very launch.)
-        const DiagJob<T> &cj = cold;
+        // A stored plan knows its marked cells: the entries of its lists whose radius field is zero -- no flags read,
+        // no plane ranked.
+        const DiagJob<T> &cj = *job.cold;
         int *s_qblk = (int *)&s_cell[0][0];              // strip << 16 | block of every query step's list
         __syncthreads();
         if (tid == 0) s_misc[9] = 0;
@@ -1055,8 +838,9 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
                 if (nnmax > 1) atomicMax(&job.flags[strip * npad + jp], nnmax);
             }
         }
+        __syncthreads();                                 // (the update below lays its own table over the cell lists)
     } else if (s_misc[4] != 0) {
-        const DiagJob<T> &cj = cold;
+        const DiagJob<T> &cj = *job.cold;
         if (wv == 0) make_prefix(false);                 // the prefix array again (the cell lists lay over it)
         __syncthreads();
         tot_packed = s_misc[7];
@@ -1078,14 +862,14 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
         }
     }
     SB_T(6);                                             // marked cells done
-    if (!FUSED && job.update) {
+    if (job.update) {
         // ---- a band step: k_wind ran ahead of the ghost rows and left this call's winds in scratch planes; thresholds,
         // scaling and state update (ref :235-266) of every band cell this workgroup queried, now that thc holds its
         // contrast.  Behind the march, not inside it: a cell's winds and state loaded in a step would drain the blocks the
         // march keeps in flight.  The cells come from the plan's lists (stored, or written by this very launch); four
         // list rows per wave in flight.  thc is read past the L1 (other waves of this workgroup wrote it). ----
         __syncthreads();
-        const DiagJob<T> &cj = cold;
+        const DiagJob<T> &cj = *job.cold;
         auto apply = [&](unsigned o) __attribute__((always_inline)) {
             const T n_thc = __hip_atomic_load(&job.thc[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sb_trigger_update<T, false>(cj, (size_t)o, n_thc, sb_trigger_load<T>(cj, (size_t)o));
@@ -1142,8 +926,9 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
             }
         }
     }
-    if (job.fold && !(SB_TRUST_LISTS && cached && job.lists_stand)) {
-        // ---- k_wind's segment lists (k_prep's work on single-domain host-model calls): sub-list `part` holds the
+    if (job.fold && !(cached && job.lists_stand)) {
+        // ---- k_wind's segment lists: compacted when the plan is made, and again only when it is made again (they follow
+        // from the band plane, as the plan does) (k_prep's work on single-domain host-model calls): sub-list `part` holds the
         // segments with band cells of its contiguous range of the band plane, in ascending order ----
         const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw;
         const unsigned cap = (unsigned)job.seg_cap;
@@ -1165,84 +950,6 @@ __device__ __forceinline__ bool strip_march(char *plan, const int *plan_gen, con
         }
     }
     SB_T(7);                                             // end
-    return true;
-}
-
-// ---- the kernels ------------------------------------------------------------------------------------------------
-// k_strip: the march as a kernel of its own, behind k_scan (band steps, sb_set_fuse(ctx, 0), grids the fused kernel
-// does not take).
-template <typename T, bool FLY>
-__global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_gen, const Moments *fold_partials, int G, StripJob<T> job) {
-    // (the three pointers the first loads of the kernel hang on come as leading arguments: with
-    // -amdgpu-kernarg-preload-count=7 they are in scalar registers when the wave starts, and the plan header, the
-    // change counter and k_scan's partial sums are requested without waiting for a load of the argument block)
-    const FusedSync none = {nullptr, nullptr, nullptr};
-    const Moments nothing = moments_empty();
-    __shared__ StripLds<T> lds;
-    (void)strip_march<T, FLY, false, false>(plan, plan_gen, fold_partials, G, job, *job.cold, none, nothing, -1, lds);
-}
-
-// k_scan_strip: k_scan's pass and the march in ONE launch (single-domain host-model calls): one persistent 1024-thread
-// workgroup per compute unit streams its share of sigma and mask, hands its shifted sums over write-through, sets up the
-// march by its stored plan -- and meets the others at a grid-wide barrier only then.  What the launch boundary between
-// k_scan and k_strip cost (the gap, the march's cold start: plan header -> steps -> first blocks, 6 us) is spent while
-// the slowest compute units finish the pass.  The plan stands from call to call (a coast does not move); a launch in
-// which it does not -- the first call, a change of the ice edge -- sends every workgroup round the long way: a real
-// release / acquire pair round a second barrier (the per-XCD L2s are not coherent with each other; in the common case
-// nothing needs them: the planes hold the values they held before the launch), then the march that plans for itself.
-// All G workgroups must be resident at once: G <= compute units, 1024 threads and the whole LDS each -- the host
-// launches it on a stream on which nothing else runs beside it.
-template <typename T>
-struct ScanStripArgs {
-    char *plan;                     // the first 7 dwords are preloaded into scalar registers (see the Makefile)
-    const int *plan_gen;
-    const Moments *fold_partials;
-    int G, pad;
-    FusedSync fs;
-    unsigned *ticket_next;          // the three words of the next launch, zeroed here
-    StripJob<T> sj;
-    DiagJob<T> job;
-};
-
-template <typename T, bool ST>
-__global__ __launch_bounds__(STRIP_NT) void k_scan_strip(ScanStripArgs<T> a) {
-    __shared__ StripLds<T> lds;
-#ifdef SB_STAMPS
-#define SB_TF(i) do { if ((threadIdx.x & 63) == 0) a.sj.stamps[(size_t)(blockIdx.x * (STRIP_NT / SB_WAVE) + (threadIdx.x >> 6)) * SB_NSTAMP + (i)] = wall_clock64(); } while (0)
-#else
-#define SB_TF(i) do { } while (0)
-#endif
-    SB_TF(24);                                           // kernel starts
-    if (blockIdx.x == 0 && threadIdx.x < 3) __hip_atomic_store(a.ticket_next + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Moments t;
-    const bool changed = sb_scan_pass<T, 2, false, ST, SB_FUSE_FILL_IN_SCAN != 0, true>(a.job, t, (unsigned)__builtin_offsetof(ScanStripArgs<T>, job));
-    if (changed && a.job.plan_gen) atomicMax(a.job.plan_gen, a.job.call_id);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the change counter has been raised before this workgroup arrives)
-    SB_TF(25);                                           // scan pass done
-    if (ST) t = block_total_shifted<STRIP_NT / SB_WAVE>(t, lds.s_wpart);
-    else __syncthreads();
-    if (strip_march<T, true, true, true>(a.plan, a.plan_gen, a.fold_partials, a.G, a.sj, a.job, a.fs, t, -1, lds)) {
-        SB_TF(26);                                       // march and epilogue done
-        if (!SB_FUSE_FILL_IN_SCAN) sb_fill_tail<T>(a.job, a.fs.ticket + 2, &lds.s_misc[11]);
-        SB_TF(27);                                       // fill done
-        return;
-    }
-    // ---- the long way round (uniform over the grid): everything this launch wrote becomes visible to everybody ----
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    int &s_pg = lds.s_misc[11];
-    __syncthreads();                                    // (everybody has left the march's LDS)
-    if (threadIdx.x == 0) {
-        unsigned seen;
-        __hip_atomic_fetch_add(a.fs.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)sb_grid_wait(a.fs.ticket + 1, (unsigned)a.G, a.fs.err, seen);
-        s_pg = __hip_atomic_load(a.plan_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const FusedSync none = {nullptr, nullptr, nullptr};
-    const Moments nothing = moments_empty();            // (nothing of this launch's first half stays live across the march)
-    (void)strip_march<T, true, false, false>(a.plan, a.plan_gen, a.fold_partials, a.G, a.sj, a.job, none, nothing, s_pg, lds);
-    if (!SB_FUSE_FILL_IN_SCAN) sb_fill_tail<T>(a.job, a.fs.ticket + 2, &lds.s_misc[11]);
 }
 
 // the hot part of the job, by value; everything else the kernel reads -- rarely -- from the copy of the whole job that
@@ -1277,26 +984,6 @@ hipError_t sb_launch_strip(const DiagJob<T> &job, int ncu, hipStream_t st) {
     else hipLaunchKernelGGL((k_strip<T, false>), gr, bl, 0, st, sj.plan, sj.plan_gen, sj.fold_partials, ncu, sj);
     return hipGetLastError();
 }
-// the fused launch: `job` as sb_launch_strip takes it (fold set), `scan_stats`: sigma's moments are formed (else the scalars
-// in job.stats stand), `tickets`: the four barrier words [this launch: 2 | the next launch: 2] and `err`, see FusedSync
-template <typename T>
-hipError_t sb_launch_scan_strip(const DiagJob<T> &job, int ncu, bool scan_stats, Moments *partials, unsigned *ticket_now,
-                                unsigned *ticket_next, unsigned *err, hipStream_t st) {
-    if (!job.wind_final || !job.t0_fly || !job.fold || job.flavour != SB_FLAVOUR_GENERIC || ncu > 0xffff) return hipErrorInvalidValue;
-    ScanStripArgs<T> a;
-    const StripJob<T> sj = strip_job<T>(job);
-    a.plan = sj.plan; a.plan_gen = sj.plan_gen; a.fold_partials = sj.fold_partials; a.G = ncu; a.pad = 0;
-    a.fs.ticket = ticket_now; a.fs.err = err; a.fs.partials = partials;
-    a.ticket_next = ticket_next;
-    a.sj = sj;
-    a.job = job;
-    const dim3 gr(ncu), bl(STRIP_NT);                   // one persistent workgroup per CU: all of them resident at once
-    if (scan_stats) hipLaunchKernelGGL((k_scan_strip<T, true>), gr, bl, 0, st, a);
-    else hipLaunchKernelGGL((k_scan_strip<T, false>), gr, bl, 0, st, a);
-    return hipGetLastError();
-}
-template hipError_t sb_launch_scan_strip<float>(const DiagJob<float> &, int, bool, Moments *, unsigned *, unsigned *, unsigned *, hipStream_t);
-template hipError_t sb_launch_scan_strip<double>(const DiagJob<double> &, int, bool, Moments *, unsigned *, unsigned *, unsigned *, hipStream_t);
 template hipError_t sb_launch_strip<float>(const DiagJob<float> &, int, hipStream_t);
 template hipError_t sb_launch_strip<double>(const DiagJob<double> &, int, hipStream_t);
 

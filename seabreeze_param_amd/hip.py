@@ -56,7 +56,8 @@ def hip_runtimes():
     """Paths of the HIP runtimes (libamdhip64) mapped into this process.  PyTorch bundles a runtime of its own and
     loads it by path; libseabreeze_hip.so asks for the soname.  So with `import torch` FIRST the library binds to
     torch's copy and the process has ONE runtime -- a torch stream handle is then a valid hipStream_t for the C ABI --
-    while with the library loaded first there are TWO, whose streams and synchronisation know nothing of each other."""
+    while with the library loaded first there are TWO, whose streams and synchronisation know nothing of each other (and
+    of which, on this pool, only the first to initialise finds the GPU)."""
     seen = []
     try:
         for ln in open("/proc/self/maps"):
@@ -70,12 +71,15 @@ def hip_runtimes():
 
 
 def torch_stream_handle(torch):
-    """The hipStream_t to hand to the `_dev` entry points from a process that also runs PyTorch: torch's current
-    stream when torch and the library share one HIP runtime, else None (NULL = the context's own stream; the caller
-    must then close every hand-over with Context.synchronize() AND torch.cuda.synchronize())."""
-    if len(hip_runtimes()) == 1:
-        return torch.cuda.current_stream().cuda_stream
-    return None
+    """The hipStream_t to hand to the `_dev` entry points from a process that also runs PyTorch: torch's current stream.
+    Valid only when torch and the library share ONE HIP runtime, i.e. when torch was imported before the library was
+    loaded; with two runtimes in a process only the one that initialises first finds the GPU at all (measured on this
+    pool: the other reports no device), so that order is refused here rather than timed wrongly."""
+    rts = hip_runtimes()
+    if len(rts) != 1:
+        raise SeabreezeHipError("torch and libseabreeze_hip.so must share one HIP runtime: import torch BEFORE the library is "
+                                f"loaded (mapped runtimes: {rts})")
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _p(a):
@@ -131,9 +135,9 @@ class Context:
         """The strip kernel keeps its plan while the band plane stands (default) or plans every call (measurement / test knob)."""
         self._chk(self.lib.sb_set_plan_cache(self.h, C.c_int(1 if on else 0)), "sb_set_plan_cache")
 
-    def set_fuse(self, on: bool):
-        """k_scan's pass and the strip kernel's march in one launch (default) or two (measurement / test knob)."""
-        self._chk(self.lib.sb_set_fuse(self.h, C.c_int(1 if on else 0)), "sb_set_fuse")
+    def set_wide_strip(self, on: bool):
+        """Radii beyond 16 in single precision: the 96-column strip kernel (default) or the tile kernel (test knob)."""
+        self._chk(self.lib.sb_set_wide_strip(self.h, C.c_int(1 if on else 0)), "sb_set_wide_strip")
 
     def set_workgroups(self, n: int):
         """Persistent workgroups of the one-per-CU kernels (0: the device's compute units); a test knob."""

@@ -41,12 +41,11 @@ def test_strip_kernels_wait_for_their_prefetched_blocks():
     if not os.path.exists(cw.OBJDUMP):
         pytest.skip("no llvm-objdump in this image")
     waits = cw.strip_kernel_waits(hip.LIB_PATH if hasattr(hip, "LIB_PATH") else os.path.join(ROOT, "seabreeze_param_amd", "libseabreeze_hip.so"))
-    # k_strip: float / double x t0 on the fly or from the plane; k_scan_strip (the fused kernel: two marches each):
-    # float / double x with or without sigma's statistics
-    assert len(waits) == 8, sorted(waits)
+    # k_strip: float / double x t0 on the fly or from the plane; k_strip32 (single precision): on the fly or from the plane
+    assert len(waits) == 6, sorted(waits)
     for name, hist in waits.items():
         need = cw.expected_depth(name)
-        assert sum(v for k, v in hist.items() if k >= need) >= cw.expected_waits(name), (name, sorted(hist.items()))
+        assert sum(v for k, v in hist.items() if k >= need) >= 3, (name, sorted(hist.items()))
 
 
 def test_no_device_means_loud_failure():

@@ -38,7 +38,7 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["kernel_ms"]["k_wind"] > 0 and rf["kernel_ms"]["k_scan_strip"] > 0 and rf["launches_per_call"] == 2
+    assert rf["kernel_ms"]["k_wind"] > 0 and rf["kernel_ms"]["k_thc"] > 0 and rf["kernel_ms"]["k_scan"] > 0 and rf["launches_per_call"] == 3
     assert d["parity"]["ok"] and max(d["parity"]["max_rel_err"].values()) < 1e-6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     # the line says which runtime ran, which stream, which BASELINE configuration (none for this grid), and which state
@@ -47,28 +47,19 @@ def test_bench_single_gpu_line():
     assert len(c["hip_runtime"]) == 1 and "torch" in c["stream"] and c["baseline_config_index"] is None
     assert "not a BASELINE.json configuration" in c["workload"] and c["plan_cache"] == "stored"
     rp = rf["replan"]
-    assert rp["ms_per_step"] > 0 and rp["k_scan_strip"] > 0 and rf["plan_cache"] == "stored"
+    assert rp["ms_per_step"] > 0 and rp["k_thc"] > 0 and rf["plan_cache"] == "stored"
 
 
-def test_bench_does_not_depend_on_the_import_order():
-    """The library loaded BEFORE torch: two HIP runtimes in the process (torch loads its bundled copy by path).  bench.py
-    must notice, run the library on its own stream, close the timed region with both synchronisations -- and arrive at
-    the same parity and a step time of the same size as in the usual order."""
-    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "512", "--ny", "384", "--nz", "8", "--steps", "20",
-            "--warmup", "3", "--cpu-budget", "1"]
-    one = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def test_bench_refuses_the_other_import_order():
+    """The library loaded BEFORE torch: two HIP runtimes in the process (torch loads its bundled copy by path), whose
+    streams and synchronisation know nothing of each other.  bench.py must say so and stop -- not print a time that
+    torch.cuda.synchronize() did not actually close."""
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "512", "--ny", "384", "--nz", "8", "--steps", "5",
+            "--warmup", "2", "--no-cpu-baseline"]
     two = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT,
                          env=dict(os.environ, SEABREEZE_BENCH_LIBRARY_FIRST="1"))
-    assert one.returncode == 0 and two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
-    d1, d2 = _line(one.stdout), _line(two.stdout)
-    assert len(d1["config"]["hip_runtime"]) == 1 and len(d2["config"]["hip_runtime"]) == 2, (d1["config"], d2["config"])
-    assert "own stream" in d2["config"]["stream"] and d2["median_ms_per_step"] is None
-    assert d2["parity"]["ok"] and d2["parity"]["max_rel_err"] == d1["parity"]["max_rel_err"]
-    # an honest time: the kernels' own event times fit inside the step in both orders
-    for d in (d1, d2):
-        ksum = sum(v for k, v in d["roofline"]["kernel_ms"].items())
-        assert d["ms_per_step"] >= 0.9 * ksum, (d["ms_per_step"], d["roofline"]["kernel_ms"])
-    assert 0.5 < d2["ms_per_step"] / d1["ms_per_step"] < 2.0, (d1["ms_per_step"], d2["ms_per_step"])
+    assert two.returncode != 0 and not [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert "HIP runtime" in two.stderr and "import torch before" in two.stderr, two.stderr[-1500:]
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -133,25 +133,22 @@ def test_wrapper_flavour_fp64(hipctx, oracles, shape, contrast_variant):
     assert c["one_class_cells"] == 0 and c["max_radius"] == orc.last_nn_max
 
 
-@pytest.fixture(params=[(16, True, True, True), (16, True, False, True), (16, True, True, False), (16, False, True, True), (24, False, True, True)],
-                ids=["fused", "fused-replan", "strip", "strip-kprep", "tiles-halo24"])
+@pytest.fixture(params=[(16, True, True), (16, True, False), (16, False, True), (24, False, True)],
+                ids=["strip", "strip-replan", "strip-kprep", "tiles-halo24"])
 def contrast_variant(request, hipctx):
     """The contrast kernels the oracle comparisons run under: the marching-strip kernel (radius hints up to 16) doing
-    k_prep's work itself and fused with k_scan's pass into one launch (the default for host-model calls on one domain)
-    -- with the plan of its march kept from call to call (the default: the first call of a test goes the long way round
-    inside the fused kernel and plans, the later ones march by the stored plan) or made afresh every call -- the same as
-    a launch of its own behind k_scan (what a band step runs), with k_prep as a kernel of its own, and the tile kernel
-    with its 24-cell halo (what a radius hint of 17..24 selects).  Results never depend on the choice."""
-    hint, fold, keep, fuse = request.param
+    k_prep's work itself (the default for host-model calls on one domain) -- with the plan of its march kept from call
+    to call (the default: the first call of a test plans, the later ones march by the stored plan) or made afresh every
+    call -- or with k_prep as a kernel of its own, and the tile kernel with its 24-cell halo (what a radius hint of
+    17..24 selects).  Results never depend on the choice."""
+    hint, fold, keep = request.param
     hipctx.set_search_radius_hint(hint)
     hipctx.set_fold(fold)
     hipctx.set_plan_cache(keep)
-    hipctx.set_fuse(fuse)
     yield hint
     hipctx.set_search_radius_hint(16)
     hipctx.set_fold(True)
     hipctx.set_plan_cache(True)
-    hipctx.set_fuse(True)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -244,6 +241,37 @@ def test_few_workgroups_march_in_rounds(hipctx, oracles, nwg):
                 _assert_close64(a, b, f"{nwg} workgroups tn={tn} {nm}")
     finally:
         hipctx.set_workgroups(0)
+
+
+@pytest.mark.parametrize("nwg", [0, 2, 5])
+def test_band_that_reaches_the_first_and_the_last_row(hipctx, oracles, nwg):
+    """Every block of most strips is active (a fabricated distance field: every cell within 14 cells of a coast is in the
+    band, poles included), so the last block of one strip and the first block of the next lie side by side in the
+    strip-major order of a workgroup's share: a run of the march must end with the strip (round 4 found the last block of
+    a strip unqueried when it did not)."""
+    nx, ny, nz = 512, 384, 2
+    dt, orc = np.float64, _omp_oracle(8)
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    cdist = orc.get_dist(coast, st.landfrac, st.lon, st.lat, maxdist=20000.0, kwin=14)
+    cdist = np.where(np.abs(cdist) < 12000.0, np.sign(cdist) * np.minimum(np.abs(cdist), 179.0), cdist)
+    band = np.abs(cdist) <= 180.0
+    assert band[:16].any() and band[-16:].any()
+    p = synth.pressure_3d(st, nz, dt)
+    so, sh = _states(ny, nx, dt, 4), _states(ny, nx, dt, 4)
+    hipctx.set_search_radius_hint(16)
+    hipctx.set_workgroups(nwg)
+    try:
+        for tn in (1, 2, 3):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            orc.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *so, halo=0, bnd=1, omp=True)
+            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+            for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
+                _assert_close64(a, b, f"{nwg} workgroups tn={tn} {nm}")
+    finally:
+        hipctx.set_workgroups(0)
+    assert hipctx.last_counters()["global_path_cells"] == 0
 
 
 def test_alternating_grids_and_contrast_kernels_in_one_context(hipctx, oracles):

@@ -40,7 +40,7 @@ def strip_kernel_waits(lib):
             for line in dis.splitlines():
                 m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
                 if m:
-                    name = m.group(1) if m.group(1).startswith(("_Z7k_strip", "_Z12k_scan_strip")) else None
+                    name = m.group(1) if m.group(1).startswith(("_Z7k_strip", "_Z9k_strip32")) else None
                     if name:
                         out[name] = collections.Counter()
                     continue
@@ -52,16 +52,12 @@ def strip_kernel_waits(lib):
 
 
 def expected_depth(name):
-    """fly (t0 derived while staging: four loads a row) -> 8, else 4; the fused kernel (k_scan_strip) always derives t0"""
-    if name.startswith("_Z12k_scan_strip"):
-        return 8
+    """fly (t0 derived while staging: four loads a row) -> 8, else 4; k_strip32 stages two pieces of a row: 16 and 8"""
+    m = re.match(r"_Z9k_strip32ILb([01])E", name)
+    if m:
+        return 16 if m.group(1) == "1" else 8
     m = re.match(r"_Z7k_stripI([fd])Lb([01])E", name)
     return 8 if m.group(2) == "1" else 4
-
-
-def expected_waits(name):
-    """three copies of the step per march; the fused kernel holds two marches (by the stored plan; planning for itself)"""
-    return 6 if name.startswith("_Z12k_scan_strip") else 3
 
 
 def check(lib):
@@ -71,7 +67,7 @@ def check(lib):
         need = expected_depth(name)
         deep = sum(v for k, v in hist.items() if k >= need)
         print(f"{name}: waits at depth >= {need}: {deep}; histogram {sorted(hist.items())}")
-        if deep < expected_waits(name):
+        if deep < 3:
             bad.append(name)
     if not waits:
         print("no k_strip kernel found")

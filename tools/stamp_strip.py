@@ -52,12 +52,6 @@ for i in range(0, NS - 9):
     if ok[:, 0].sum() == 0:
         break
     print(f"   step {i:2d}: n {int(ok[:, 0].sum()):3d}   {np.mean((b - a)[:, 0][ok[:, 0]]):.2f} | {np.mean((b - a)[:, 15][ok[:, 15]]) if ok[:, 15].any() else float('nan'):.2f}")
-if t[:, :, 24].max() > 0:                              # the fused kernel (k_scan_strip)
-    f0 = t[:, :, 24].min()
-    rel = lambda i: t[:, :, i] - f0
-    print(f"fused kernel: span {t[:, :, 27].max() - f0:.2f} us; scan pass done mean {rel(25).mean():.2f} [min {rel(25).min():.2f} max {rel(25).max():.2f}]; "
-          f"march entered (strip start) mean {rel(0).mean():.2f}; first barrier of the march reached {rel(1).mean():.2f} [max {rel(1).max():.2f}]; march begins {rel(4).mean():.2f} [max {rel(4).max():.2f}]; "
-          f"march done {rel(5).mean():.2f} [max {rel(5).max():.2f}]; epilogue done {rel(26).mean():.2f} [max {rel(26).max():.2f}]; fill done {rel(27).mean():.2f} [max {rel(27).max():.2f}]")
 life = t[:, :, 7].max(axis=1) - t[:, :, 0].min(axis=1)
 print(f"workgroup life: mean {life.mean():.2f} max {life.max():.2f} min {life.min():.2f} us; march (wave 0) mean {np.mean(t[:, 0, 5] - t[:, 0, 4]):.2f} max {np.max(t[:, 0, 5] - t[:, 0, 4]):.2f}")
 # what a workgroup's life is made of: its steps by kind, from the stored plan; least squares
