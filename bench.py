@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
+    ap.add_argument("--no-replan", action="store_true",
+                    help="skip the extra passes with sb_set_plan_cache(ctx, 0) (profiling runs: rocprofv3's per-kernel averages "
+                         "then refer to the stored-plan state alone)")
     ap.add_argument("--static-sigma", action="store_true",
                     help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
     args = ap.parse_args()
@@ -444,7 +447,7 @@ def main():
     # ---- the same K steps with the contrast kernel's plan remade in every call (sb_set_plan_cache(0)): what a first
     # call, or a call after the ice edge moved, costs.  The headline above is the stored-plan state. -------------
     replan = None
-    if world == 1:
+    if world == 1 and not args.no_replan:
         ctx.set_plan_cache(False)
         el_r, tn = timed_pass(tn, W)
         ctx.profile_begin(K)

@@ -156,6 +156,12 @@ struct sb_ctx {
     void *stats = nullptr;      // 4 x double
     int *counters = nullptr;    // 2 ints
     int *seg_count = nullptr;   // SB_SEG_PARTS ints: entries in each sub-list of segments (k_prep -> k_wind)
+    // get_dist's coordinate tables (device: `vecs`): the coordinates they were made from, the host copy the upload reads,
+    // and what the host found out about the coordinates' order
+    std::vector<unsigned char> dist_key, dist_hv;
+    bool dist_ordered = false;
+    double dist_maxstep = 0.0;
+    hipStream_t dist_upload_stream = nullptr;   // the stream the tables were uploaded on, until another stream has waited for it
     // staging buffers for the host-pointer entry points
     std::vector<DevBuf> stage;
     // geometry of the last diag call (for sb_last_counters)
@@ -172,6 +178,8 @@ struct sb_ctx {
     hipStream_t aux_stream = nullptr;   // communication of a band step runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mom = nullptr;
     Moments *band_moments_out = nullptr;   // set around phase 1 of a band step: where k_scan leaves this band's moments
+    int band_geo = 0;                   // set around a band step on a strip kernel: GEO_BAND_* (which ghost cells of theta follow from
+                                        // its interior and are not read)
     DevBuf band_mom;                    // [5 own moments | 5 x nranks gathered]
     void *rccl_lib = nullptr;
     void *comm = nullptr;
@@ -214,6 +222,7 @@ Geo make_geo(int nx, int ny, int h, int bnd, int rows) {
     g.nxh = nx + 2 * h; g.nyh = ny + 2 * h;
     g.nw = (g.nxh + 63) / 64;
     g.bnd = bnd; g.rows = rows;
+    g.band = 0;
     return g;
 }
 
@@ -223,6 +232,15 @@ int pick_halo(const sb_ctx *c) {
     if (r <= 16) return 16;
     if (r <= 24) return 24;
     return SB_MAX_LDS_HALO;
+}
+
+// does a marching-strip kernel run the contrast for this precision and domain (else: the tile kernel)?  As run_diag decides.
+template <typename T>
+static bool strip_kernel_runs(const sb_ctx *c, int nx, int rows) {
+    const int H = pick_halo(c);
+    int tx, ty;
+    if (H > 16) return sizeof(T) == 4 && !c->no_wide_strip && sb_strip32_shape(nx, rows, &tx, &ty);
+    return sb_strip_shape(nx, rows, &tx, &ty);
 }
 
 // sigma's statistics of an earlier complete call still stand (opt-in, same array, same shape)
@@ -435,6 +453,7 @@ int seabreeze_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, 
     if (tun) d = *tun;
     DiagJob<T> job{};
     job.g = make_geo<T>(nx, ny, halo, bnd, ny);
+    if (bnd == SB_BND_HALO) job.g.band = c->band_geo;    // (a band step whose strip kernel reads no east-west / polar ghost cells of theta)
     job.nz = nz;
     job.flavour = SB_FLAVOUR_GENERIC;
     job.tn = tn;
@@ -460,6 +479,8 @@ template <typename T>
 int sigma_moments_dev(sb_ctx *c, int nx, int ny, int halo, const T *sigma, double *moments5, void *stream);
 template <typename T>
 int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream);
+template <typename T>
+int exchange_rows_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream);
 
 // One model step of a latitude band: the communication (this band's sigma moments and their all-gather, theta's
 // ghost rows) runs on the context's second stream while k_scan, k_prep and k_wind, which need neither, run
@@ -494,9 +515,18 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     // RCCL operations in this order), while k_scan and k_wind run on the caller's stream.
     hipError_t he = hipEventRecord(c->ev_fork, st);
     if (he == hipSuccess) he = hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0);
-    if (he != hipSuccess) { c->gathered = saved_g; c->ngathered = saved_n; return hipfail(c, he, "band step fork"); }
-    // The ghost rows of theta first: they depend on nothing this step computes.
-    rc = swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream);
+    if (he != hipSuccess) { c->gathered = saved_g; c->ngathered = saved_n; c->band_geo = 0; return hipfail(c, he, "band step fork"); }
+    // The ghost rows of theta first: they depend on nothing this step computes.  On a strip kernel only the rows that
+    // come from a NEIGHBOUR travel: the east-west ghost columns (the periodic wrap of the row itself) and the ghost rows
+    // beyond a pole (the edge row again) follow from theta's interior, and the strip kernels take them from there by index
+    // arithmetic (Geo::band) -- no fill kernel on the communication stream, three launches per band step (round 3: four,
+    // and the fill, running behind the caller's stream's kernels rather than beside them, held the join up).  The tile
+    // kernel (double precision, radii beyond 16) reads every ghost cell as filled: the whole swap_bounds for it.
+    const bool folds = strip_kernel_runs<T>(c, nx, ny) && nx > 96 + 2;
+    const int band_geo = folds ? (GEO_BAND_EW | (c->rank == 0 ? GEO_BAND_SOUTH : 0) | (c->rank == c->nranks - 1 ? GEO_BAND_NORTH : 0)) : 0;
+    rc = folds ? exchange_rows_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream)
+               : swap_bounds_dev<T>(c, theta, nx, ny, halo, (void *)c->aux_stream);
+    c->band_geo = band_geo;
     // Phase 1 on the caller's stream: k_scan -- whose last workgroup merges this band's sigma moments and leaves them for
     // the all-gather (one rank: in the gathered set itself) -- then k_wind.  (The moments used to be formed by a kernel
     // of their own on the communication stream; with the caller's stream filling every CU that kernel ran behind
@@ -505,9 +535,16 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
     if (!rc) rc = seabreeze_diag_dev<T>(c, timestep_s, tn, nx, ny, nz, halo, SB_BND_HALO, p, u, v, theta, mask, z, sigma, ws, wd,
                                         thc, sb_con, tun, (void *)st, 1);
     c->band_moments_out = nullptr;
-    if (!rc && !reuse && c->nranks > 1) {
-        he = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);          // (recorded behind k_scan by phase 1)
-        if (he != hipSuccess) rc = hipfail(c, he, "band step moments event");
+    // The all-gather is enqueued in EVERY step of a multi-rank run, whether or not this rank keeps its sigma statistics
+    // (sb_set_static_sigma): whether a rank keeps them is its own business -- its sigma pointer, its shape, the step in
+    // which it switched the option -- and ranks that disagreed about a collective used to hang (round 3 documented that as
+    // a rule for the caller; now there is nothing to agree on).  A rank that keeps its statistics contributes the moments
+    // of its band it formed then (they stand: its sigma did), a rank that forms them anew receives everybody's.
+    if (!rc && c->nranks > 1) {
+        if (!reuse) {
+            he = hipStreamWaitEvent(c->aux_stream, c->ev_mom, 0);      // (recorded behind k_scan by phase 1)
+            if (he != hipSuccess) rc = hipfail(c, he, "band step moments event");
+        }
         if (!rc) rc = sb_allgather_moments_dev(c, mine, gath, (void *)c->aux_stream);
     }
     // (whatever happened on the way: the second stream is joined into the caller's again)
@@ -518,6 +555,7 @@ int band_diag_dev(sb_ctx *c, T timestep_s, int tn, int nx, int ny, int nz, int h
                                         ws, wd, thc, sb_con, tun, (void *)st, 2);
     c->gathered = saved_g;
     c->ngathered = saved_n;
+    c->band_geo = 0;
     return rc;
 }
 
@@ -974,37 +1012,65 @@ int get_dist_dev(sb_ctx *c, int nx, int ny, const T *coast, const T *mask, const
     }
     if ((size_t)(64 + 2 * k) * (SB_DIST_TY + 2 * k) > 64 * 1024)
         return fail(c, SB_ERR_ARG, "get_dist: window too large for the LDS tile");
-    // phi = d2r*lat, folded lon in radians (ref: sobel.f90:130,165-174), host side: multiplies only
-    const T pi = T(3.1415926), d2r = pi / T(180.0);
-    std::vector<T> hv((size_t)3 * nx + ny);
-    for (int i = 0; i < ny; ++i) hv[i] = d2r * lat[i];
-    for (int j = 0; j < nx; ++j) hv[ny + j] = (lon[j] > T(180)) ? d2r * (lon[j] - T(360.)) : d2r * lon[j];
-    // half-angle tables of the folded longitudes (k_dist_bits, fp64: sin((l1 - l2) / 2) by the difference formula)
-    for (int j = 0; j < nx; ++j) { hv[ny + nx + j] = std::sin(hv[ny + j] / T(2)); hv[ny + 2 * (size_t)nx + j] = std::cos(hv[ny + j] / T(2)); }
-    int rc = ensure(c, c->vecs, hv.size() * sizeof(T));
-    if (rc) return rc;
+    // The coordinate tables on the device -- phi = d2r*lat, the folded longitudes in radians (ref: sobel.f90:130,165-174),
+    // sin and cos of half of them (k_dist_bits, fp64) -- and what the host derives from the coordinates (may the kernel keep
+    // only the nearest hit per side of a row?) stand for as long as the coordinates do: they are keyed on the CONTENT of
+    // lon and lat (a byte comparison of two short vectors), made and uploaded when it changes, and left alone otherwise --
+    // a `_dev` call then enqueues two kernels and returns, without a copy and without a synchronisation (round 3
+    // recomputed, uploaded and waited in every call: a third of get_dist's 230 us).
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->vecs.p, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));   // hv is a local: the copy must land before it dies
+    const size_t kb = ((size_t)nx + ny) * sizeof(T);
+    bool same = c->dist_key.size() == kb + 3 * sizeof(int) && c->vecs.p != nullptr;
+    const int dims[3] = {nx, ny, (int)sizeof(T)};
+    if (same) same = std::memcmp(c->dist_key.data(), dims, sizeof(dims)) == 0 &&
+                     std::memcmp(c->dist_key.data() + sizeof(dims), lon, (size_t)nx * sizeof(T)) == 0 &&
+                     std::memcmp(c->dist_key.data() + sizeof(dims) + (size_t)nx * sizeof(T), lat, (size_t)ny * sizeof(T)) == 0;
+    int rc;
+    if (!same) {
+        // (the tables of the call before may still be on their way from the host vector that is rewritten now)
+        if (!c->dist_hv.empty()) HIPCHK(c, hipDeviceSynchronize());
+        c->dist_key.clear();
+        const T pi = T(3.1415926), d2r = pi / T(180.0);
+        c->dist_hv.resize(((size_t)3 * nx + ny) * sizeof(T));
+        T *hv = (T *)c->dist_hv.data();
+        for (int i = 0; i < ny; ++i) hv[i] = d2r * lat[i];
+        for (int j = 0; j < nx; ++j) hv[ny + j] = (lon[j] > T(180)) ? d2r * (lon[j] - T(360.)) : d2r * lon[j];
+        for (int j = 0; j < nx; ++j) { hv[ny + nx + j] = std::sin(hv[ny + j] / T(2)); hv[ny + 2 * (size_t)nx + j] = std::cos(hv[ny + j] / T(2)); }
+        if ((rc = ensure(c, c->vecs, c->dist_hv.size()))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->vecs.p, hv, c->dist_hv.size(), hipMemcpyHostToDevice, st));   // (dist_hv lives on with the context)
+        c->dist_upload_stream = st;
+        // k_dist_bits may keep only the nearest hit on each side of a source row when the haversine term grows with
+        // the index distance inside the window: longitudes that step strictly eastwards once round the circle (the
+        // closing step from the last column to the first included); and may stop its walk over the rows early when the
+        // latitudes step one way.  (Whether the window stays short of half the circle depends on k: checked per call.)
+        double turn = 0.0, maxstep = 0.0;
+        bool mono = nx > 1;
+        for (int j = 0; j < nx && mono; ++j) {
+            double d = std::fmod((double)lon[(j + 1) % nx] - (double)lon[j], 360.0);
+            if (d < 0) d += 360.0;
+            mono = d > 1.0e-6;
+            turn += d;
+            maxstep = d > maxstep ? d : maxstep;
+        }
+        bool latmono = true;                      // sp^2 grows with the row distance: latitudes step one way
+        for (int i = 0; i + 2 < ny && latmono; ++i)
+            latmono = ((double)lat[i + 1] - (double)lat[i]) * ((double)lat[i + 2] - (double)lat[i + 1]) > 0.0;
+        for (int i = 0; i < ny && latmono; ++i) latmono = std::fabs((double)lat[i]) <= 90.0;
+        c->dist_ordered = mono && latmono && turn < 360.0 + 1.0e-3;
+        c->dist_maxstep = maxstep;
+        c->dist_key.resize(kb + sizeof(dims));
+        std::memcpy(c->dist_key.data(), dims, sizeof(dims));
+        std::memcpy(c->dist_key.data() + sizeof(dims), lon, (size_t)nx * sizeof(T));
+        std::memcpy(c->dist_key.data() + sizeof(dims) + (size_t)nx * sizeof(T), lat, (size_t)ny * sizeof(T));
+    }
+    if (same && c->dist_upload_stream && c->dist_upload_stream != st) {
+        // (the tables were uploaded on another stream: once, make sure they have landed before this stream reads them)
+        HIPCHK(c, hipStreamSynchronize(c->dist_upload_stream));
+        c->dist_upload_stream = nullptr;
+    }
     const T *dphi = (const T *)c->vecs.p, *dlam = dphi + ny;
     if ((rc = ensure(c, c->coastbits, (size_t)ny * ((nx + 63) / 64) * sizeof(uint64_t)))) return rc;
-    // k_dist_bits may keep only the nearest hit on each side of a source row when the haversine term grows with
-    // the index distance inside the window: longitudes that step strictly eastwards once round the circle (the
-    // closing step from the last column to the first included) and k steps that stay short of half of it
-    double turn = 0.0, maxstep = 0.0;
-    bool mono = nx > 1;
-    for (int j = 0; j < nx && mono; ++j) {
-        double d = std::fmod((double)lon[(j + 1) % nx] - (double)lon[j], 360.0);
-        if (d < 0) d += 360.0;
-        mono = d > 1.0e-6;
-        turn += d;
-        maxstep = d > maxstep ? d : maxstep;
-    }
-    bool latmono = true;                      // sp^2 grows with the row distance: latitudes step one way
-    for (int i = 0; i + 2 < ny && latmono; ++i)
-        latmono = ((double)lat[i + 1] - (double)lat[i]) * ((double)lat[i + 2] - (double)lat[i + 1]) > 0.0;
-    for (int i = 0; i < ny && latmono; ++i) latmono = std::fabs((double)lat[i]) <= 90.0;
-    const int nearest = (mono && latmono && turn < 360.0 + 1.0e-3 && (double)k * maxstep < 170.0) ? 1 : 0;
+    const int nearest = (c->dist_ordered && (double)k * c->dist_maxstep < 170.0) ? 1 : 0;
     HIPCHK(c, sb_launch_dist<T>(coast, mask, dphi, dlam, dlam + nx, dlam + 2 * (size_t)nx, cdist, nx, ny, k, maxdist,
                                 (uint64_t *)c->coastbits.p, nearest, st));
     // a distance field made here bounds the search radius of the following diag calls
@@ -1364,6 +1430,34 @@ int rccl_load(sb_ctx *c) {
         ncclResult_t r__ = (call);                                                                    \
         if (r__ != ncclSuccess) return fail((c), SB_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r__)); \
     } while (0)
+
+// the north-south rows of swap_bounds alone: my first / last `halo` interior rows out, the neighbours' into my ghost rows
+template <typename T>
+int exchange_rows_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream) {
+    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
+    if (!field || nx < 1 || ny < 1 || halo < 0) return fail(c, SB_ERR_ARG, "bad swap_bounds arguments");
+    if (halo == 0 || c->nranks < 2) return SB_OK;
+    if (ny < halo) return fail(c, SB_ERR_ARG, "band thinner than the halo");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const size_t rowlen = (size_t)nx + 2 * halo, slab = rowlen * halo;
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    const bool south = c->rank == 0, north = c->rank == c->nranks - 1;
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(c, g_rccl.GroupStart());
+    if (!south) {
+        NCCLCHK(c, g_rccl.Send(field + slab, slab, dt, c->rank - 1, comm, st));
+        NCCLCHK(c, g_rccl.Recv(field, slab, dt, c->rank - 1, comm, st));
+        c->rep_rccl += 2;
+    }
+    if (!north) {
+        NCCLCHK(c, g_rccl.Send(field + rowlen * ny, slab, dt, c->rank + 1, comm, st));
+        NCCLCHK(c, g_rccl.Recv(field + rowlen * (ny + halo), slab, dt, c->rank + 1, comm, st));
+        c->rep_rccl += 2;
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+    c->rep_groups += 1;
+    return SB_OK;
+}
 
 template <typename T>
 int swap_bounds_dev(sb_ctx *c, T *field, int nx, int ny, int halo, void *stream) {

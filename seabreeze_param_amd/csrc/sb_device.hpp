@@ -197,12 +197,24 @@ struct Geo {
     int nw;          // 64-bit words per row of the bit planes (ceil(nxh / 64))
     int bnd;         // BND_*
     int rows;        // rows processed: ny (generic) or ny-1 (wrapper, ref: seabreeze_diag_python.f90:165)
+    int band;        // BND_HALO only, a latitude band of a multi-GPU run (GEO_BAND_*): which ghost cells of the per-step field
+                     // theta the kernels do NOT read because they follow from its interior -- the east-west ghost columns
+                     // (the band holds full longitude circles: the periodic wrap is index arithmetic) and the ghost rows
+                     // beyond a pole (the reference's latitude clamp: the edge row again).  0: every ghost cell is read as
+                     // the caller filled it (the UM layout, a band run that fills them: sb_swap_bounds / sb_fill_ghosts).
 };
+enum { GEO_BAND_EW = 1, GEO_BAND_SOUTH = 2, GEO_BAND_NORTH = 4 };
 
 // Map an interior 0-based (xs, ys), possibly outside [0,nx) x [0,ny), to coordinates in
 // the (nxh, nyh) arrays.  Returns false when the cell does not exist (BND_HALO only).
 __device__ __forceinline__ bool sb_map_cell(const Geo &g, int xs, int ys, int &X, int &Y) {
     if (g.bnd == BND_HALO) {
+        if (g.band & GEO_BAND_EW) {
+            int m = xs % g.nx;
+            xs = m < 0 ? m + g.nx : m;
+        }
+        if ((g.band & GEO_BAND_SOUTH) && ys < 0) ys = 0;
+        if ((g.band & GEO_BAND_NORTH) && ys >= g.ny) ys = g.ny - 1;
         X = xs + g.h;
         Y = ys + g.h;
         return X >= 0 && X < g.nxh && Y >= 0 && Y < g.nyh;

@@ -334,6 +334,14 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
 
     const bool fastx = g.nx > S32_W + 2;               // one conditional add wraps every column of a staged row
     const bool limited = g.bnd == BND_HALO;
+    // how far a window round (x, y) may reach inside a ghost-celled frame: the ghost width beyond the interior -- except
+    // in the directions in which a band's frame is not an edge at all (round the circle; beyond a pole)
+    const int big_reach = 1 << 20;
+    auto frame_reach = [&](int x, int y) __attribute__((always_inline)) -> int {
+        const int rx = (g.band & GEO_BAND_EW) ? big_reach : min(x + g.h, g.nx - 1 - x + g.h);
+        const int rs = (g.band & GEO_BAND_SOUTH) ? big_reach : y + g.h, rn = (g.band & GEO_BAND_NORTH) ? big_reach : g.ny - 1 - y + g.h;
+        return min(rx, min(rs, rn));
+    };
 
     // the lane's columns of the strip the loads are issued for (segment A: column lane; segment B: column 64 + lane, lanes
     // 0 .. 31): byte offsets in a field row and in a row of the land-side plane, bit in the 32-bit word (0: no such cell)
@@ -342,7 +350,11 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
     auto column_of = [&](int xs, bool live, unsigned &colb, unsigned &clsb, unsigned &lbit) __attribute__((always_inline)) {
         bool ok = live;
         int Xc = 0;
-        if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = ok && Xc >= 0 && Xc < g.nxh; }
+        if (g.bnd == BND_HALO) {
+            int xw = xs;
+            if (g.band & GEO_BAND_EW) xw = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);   // (a band holds whole circles; nx > 96 + 2)
+            Xc = xw + g.h; ok = ok && Xc >= 0 && Xc < g.nxh;
+        }
         else if (fastx) {
             if (g.bnd == BND_WRAPPER) {
                 int m = xs + 1;
@@ -371,7 +383,12 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
         const int ys = (jp - HB) * C + wv;              // interior row (may lie outside the grid: clamped or absent)
         int Yr;
         bool rowok = true;
-        if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
+        if (g.bnd == BND_HALO) {
+            int yw = ys;
+            if ((g.band & GEO_BAND_SOUTH) && yw < 0) yw = 0;          // beyond a pole: the edge row again (the latitude clamp)
+            if ((g.band & GEO_BAND_NORTH) && yw >= g.ny) yw = g.ny - 1;
+            Yr = yw + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0;
+        }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
         const size_t rowb = (size_t)((unsigned)Yr * (unsigned)g.nxh) * sizeof(T), wordb = (size_t)((unsigned)Yr * (unsigned)g.nw) * 8u;
         RA.th = *(const T *)((const char *)job.theta + rowb + cc_colA);                 // (theta is the t0 plane unless FLY)
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
         };
         if (!cached) {
             int lim = S32_HMAX;
-            if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));   // uniform branch
+            if (limited) lim = min(lim, frame_reach(x, y));   // uniform branch
             const int limc = max(lim, 1);
             // land-side count of the square of radius rad: the low 16 bits of the land-side table's six-entry combination
             const unsigned short *c16 = (const unsigned short *)sL;
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
     auto slow_cell = [&](const DiagJob<T> &cj, int x, int y, int &nnmax) __attribute__((always_inline)) {
         const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;
         int cap = g.nx + g.ny;
-        if (limited) cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
+        if (limited) cap = min(cap, frame_reach(x, y));
         bool one_class;
         const T cg = contrast_global(cj, x, y, cap, sd, rr, nnmax, one_class);
         atomicAdd(&cj.counters[0], 1);

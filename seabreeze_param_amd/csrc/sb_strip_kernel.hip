@@ -426,6 +426,14 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
 
     const bool fastx = g.nx > W + 2;                   // one conditional add wraps every column of a staged row
     const bool limited = g.bnd == BND_HALO;
+    // how far a window round (x, y) may reach inside a ghost-celled frame: the ghost width beyond the interior -- except
+    // in the directions in which a band's frame is not an edge at all (round the circle; beyond a pole)
+    const int big_reach = 1 << 20;
+    auto frame_reach = [&](int x, int y) __attribute__((always_inline)) -> int {
+        const int rx = (g.band & GEO_BAND_EW) ? big_reach : min(x + g.h, g.nx - 1 - x + g.h);
+        const int rs = (g.band & GEO_BAND_SOUTH) ? big_reach : y + g.h, rn = (g.band & GEO_BAND_NORTH) ? big_reach : g.ny - 1 - y + g.h;
+        return min(rx, min(rs, rn));
+    };
 
     // the lane's column of the strip the loads are issued for: byte offsets in a field row and in a row of the
     // land-side plane, bit in the 32-bit word (-1: no such cell); recomputed when the strip changes
@@ -442,7 +450,11 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
             const int xs = strip * SW - H + lane;
             bool ok = true;
             int Xc = 0;
-            if (g.bnd == BND_HALO) { Xc = xs + g.h; ok = Xc >= 0 && Xc < g.nxh; }
+            if (g.bnd == BND_HALO) {
+                int xw = xs;
+                if (g.band & GEO_BAND_EW) xw = xs < 0 ? xs + g.nx : (xs >= g.nx ? xs - g.nx : xs);   // (a band holds whole circles; nx > 64 + 2)
+                Xc = xw + g.h; ok = Xc >= 0 && Xc < g.nxh;
+            }
             else if (fastx) {
                 if (g.bnd == BND_WRAPPER) {
                     int m = xs + 1;
@@ -461,7 +473,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         const int ys = (jp - 1) * C + wv;               // interior row (may lie outside the grid: clamped or absent)
         int Yr;
         bool rowok = true;
-        if (g.bnd == BND_HALO) { Yr = ys + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0; }
+        if (g.bnd == BND_HALO) {
+            int yw = ys;
+            if ((g.band & GEO_BAND_SOUTH) && yw < 0) yw = 0;          // beyond a pole: the edge row again (the latitude clamp)
+            if ((g.band & GEO_BAND_NORTH) && yw >= g.ny) yw = g.ny - 1;
+            Yr = yw + g.h; rowok = Yr >= 0 && Yr < g.nyh; Yr = rowok ? Yr : 0;
+        }
         else Yr = ys < 0 ? 0 : (ys >= g.ny ? g.ny - 1 : ys);
         // (a scalar base -- field pointer plus the row's offset -- and the lane's 32-bit column offset: two scalar
         // registers per field where a buffer descriptor takes four)
@@ -634,7 +651,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         const unsigned cx = (unsigned)(lx + H + 1);      // its table column
         if (!cached) {
             int lim = H;
-            if (limited) lim = min(lim, min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h)));   // uniform branch
+            if (limited) lim = min(lim, frame_reach(x, y));   // uniform branch
             const int limc = max(lim, 1);
             // land-side count of the square of radius rad: C(r1,a1) - C(r0,a1) - C(r1,a0) + C(r0,a0),
             // r0 = rho-rad-1, r1 = rho+rad, a0 = cx-rad-1, a1 = cx+rad
@@ -800,7 +817,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
     auto slow_cell = [&](const DiagJob<T> &cj, int x, int y, int &nnmax) __attribute__((always_inline)) {
         const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;
         int cap = g.nx + g.ny;
-        if (limited) cap = min(min(x + g.h, g.nx - 1 - x + g.h), min(y + g.h, g.ny - 1 - y + g.h));
+        if (limited) cap = min(cap, frame_reach(x, y));
         bool one_class;
         const T cg = contrast_global(cj, x, y, cap, sd, rr, nnmax, one_class);
         atomicAdd(&cj.counters[0], 1);

@@ -99,9 +99,11 @@ def test_band_step_single_rank_equals_global(oracles, with_comm, static_sigma, c
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
         # what a band step enqueues (one rank: its moments are the gathered set, no neighbours to send to):
-        # on the communication stream the ghost fill; on the caller's k_scan (whose last workgroup publishes the band's moments), k_prep, k_wind,
-        # the strip kernel (which merges the gathered moments itself) and the update; with static sigma the statistics go.  With the contrast kernel ahead of k_wind (sb_set_band_order) k_prep and the update go too.
-        n0 = 4 if contrast_first else 5
+        # nothing on the communication stream (theta's east-west ghost columns and the rows beyond the poles are index arithmetic in
+        # the strip kernel since round 4: no fill kernel); on the caller's k_scan (whose last workgroup publishes the band's
+        # moments), k_prep, k_wind, the strip kernel (which merges the gathered moments itself and applies the update); with
+        # static sigma the statistics go.  With the contrast kernel ahead of k_wind (sb_set_band_order) k_prep goes too.
+        n0 = 3 if contrast_first else 4
         assert reports[0] == dict(kernel_launches=n0, rccl_ops=0, rccl_groups=0, d2d_copies=0)
         n1 = n0 if contrast_first else n0 - 1            # (from the second step on the segment lists of the step before stand: no k_prep)
         later = dict(reports[0], kernel_launches=n1)     # (static sigma: k_scan skips the statistics -- the same launches)
@@ -206,7 +208,7 @@ def test_band_step_follows_a_changing_coast(oracles):
             for nm, a, b in zip(("ws", "wd", "thc", "sb_con"), state, ref):
                 err = np.max(np.abs(a.cpu().numpy() - b) / np.maximum(np.abs(b), 1e-2))
                 assert err < 1e-7, f"step {tn} {nm}: {err}"
-        assert launches == [5, 4, 4, 4, 4, 4], launches     # k_prep in the first step only
+        assert launches == [4, 3, 3, 3, 3, 3], launches     # k_prep in the first step only
     finally:
         ctx.close()
 

@@ -44,7 +44,10 @@ def _check_dist(h, o, what, rel):
 
 @pytest.mark.parametrize("prec", [8, 4])
 @pytest.mark.parametrize("shape,kwin", [((200, 90), 1), ((200, 90), 5), ((130, 64), 15), ((130, 40), 31), ((64, 33), 31),
-                                        ((70, 30), 20)])
+                                        ((70, 30), 20),
+                                        # grids of at least 2k + 257 columns take the kernel that stages a workgroup's reach in
+                                        # LDS (narrower ones the per-target walk): whole and ragged workgroups and bit words
+                                        ((512, 40), 15), ((330, 70), 31), ((600, 33), 7), ((391, 47), 30), ((258, 20), 0)])
 def test_get_dist_global_seam(hipctx, oracles, shape, kwin, prec):
     nx, ny = shape
     dt, orc = (np.float64, oracles[8]) if prec == 8 else (np.float32, oracles[4])
@@ -64,8 +67,12 @@ def test_get_dist_every_hit_path(hipctx, oracles, lons):
     """Coordinates for which the haversine term need not grow with the index distance inside a row, or with the row
     distance: the host must leave the shortcuts of k_dist_bits off (or, for descending latitudes, may leave them
     on), and the kernel must still give the reference's minimum."""
-    nx, ny, kwin = 150, 60, 9
     dt, orc = np.float64, oracles[8]
+    for nx, ny, kwin in ((150, 60, 9), (420, 40, 9)):            # the per-target walk | the staged kernel
+        _every_hit_path(hipctx, orc, dt, lons, nx, ny, kwin)
+
+
+def _every_hit_path(hipctx, orc, dt, lons, nx, ny, kwin):
     _, lat = synth.grid(nx, ny)
     lon = {"regional": np.linspace(100.0, 160.0, nx),                       # closing step of 300 degrees
            "shuffled": np.random.default_rng(5).permutation(np.linspace(0.0, 357.6, nx)),
@@ -108,3 +115,26 @@ def test_get_edges_ragged_blocks(hipctx, oracles, shape, prec):
         o = orc.get_edges(land, ice, rule=rule, bnd=bnd_o)
         h = hipctx.get_edges(land, ice, rule=rule, bnd=bnd_h)
         assert np.array_equal(h, o), f"{shape} rule={rule} bnd={bnd_o}: {np.count_nonzero(h != o)} cells differ"
+
+
+@pytest.mark.parametrize("shape,prec", [((2560, 1920), 8), ((5120, 3840), 4)], ids=["N1280-fp64", "N2560-fp32"])
+def test_get_dist_at_baseline_sizes_vs_oracle(hipctx, shape, prec):
+    """The distance field of BASELINE configs[2] and configs[3] themselves -- window of 15 and 30 cells from the grid
+    spacing at 70 degrees (ref: sobel.f90:129-137) -- against the oracle's serial sweep (OpenMP over rows here: the gather
+    form of the oracle is order-free), every cell."""
+    import os
+    from oracle.pyoracle import Oracle
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
+    nx, ny = shape
+    dt = np.float64 if prec == 8 else np.float32
+    orc = Oracle(prec, omp=True)
+    st = synth.static_fields(nx, ny, dt)
+    coast = orc.get_edges(st.landfrac, st.icefrac)
+    assert np.array_equal(hipctx.get_edges(st.landfrac, st.icefrac), coast)
+    o = orc.get_dist(coast, st.landfrac, st.lon, st.lat)
+    h = hipctx.get_dist(coast, st.landfrac, st.lon, st.lat)
+    assert hip.dist_window(st.lon, st.lat) == (15 if nx == 2560 else 30)
+    _check_dist(h, o, f"{shape}", 1e-12 if prec == 8 else 2e-6)
+    assert np.all(np.abs(h[coast > 0]) == 0.5)                    # a coast cell's own distance (SURVEY.md section 4)
+    # a second call with the same coordinates takes the kept tables (no upload, no synchronisation): same field
+    assert np.array_equal(hipctx.get_dist(coast, st.landfrac, st.lon, st.lat), h)
