@@ -269,8 +269,6 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=1,
                     help="extra K-step passes with HIP events around every kernel (0 = events inside the timed pass)")
     ap.add_argument("--no-fold", action="store_true", help="measurement: k_prep as a kernel of its own (sb_set_fold(ctx, 0))")
-    ap.add_argument("--fill-in-scan", action="store_true",
-                    help="measurement: k_scan writes the fill value outside the band itself (sb_set_fill_in_strip(ctx, 0))")
     ap.add_argument("--no-replan", action="store_true",
                     help="skip the extra passes with sb_set_plan_cache(ctx, 0) (profiling runs: rocprofv3's per-kernel averages "
                          "then refer to the stored-plan state alone)")
@@ -324,8 +322,6 @@ def main():
                          "the library is loaded -- refusing to time kernels torch's synchronisation cannot see")
     if args.no_fold:
         ctx.set_fold(False)
-    if args.fill_in_scan:
-        ctx.set_fill_in_strip(False)
     if world > 1 and comm == "native":
         # rank 0 makes the RCCL id, gloo hands it round, every rank joins; all ranks agree on the outcome
         uid = [hip.comm_unique_id() if rank == 0 else None]
@@ -503,7 +499,7 @@ def main():
             "search_halo": kwin + 1,
             "parallelism": f"latband{world}",
             "variant": ("static-sigma (opt-in; not the reference's per-call statistics)" if args.static_sigma else "default")
-                       + (", k_prep as its own kernel" if args.no_fold else "") + (", fill value written by k_scan" if args.fill_in_scan else ""),
+                       + (", k_prep as its own kernel" if args.no_fold else ""),
             "comm": (comm + ("-rccl" if comm == "native" else "-" + dist.get_backend())) if world > 1 else "none",
             "multi_rank_rccl": "unmeasured on hardware so far (one GPU per box in the build pool)" if world == 1 else "this run",
             "input_gen_s": round(gen_s, 1),

@@ -98,10 +98,6 @@ int  sb_set_plan_cache(sb_ctx *ctx, int on);
    windows of up to 31 cells from LDS (on, the default); off: the tile kernel, as in double precision.  A measurement and
    test knob: results agree to single-precision rounding of the window means.                                      */
 int  sb_set_wide_strip(sb_ctx *ctx, int on);
-/* Single-domain host-model calls on a strip kernel: the value outside the coastal band (0.0, ref:
-   generic/sea_breeze_diag.f90:174-176) is written by the strip kernel behind its march and k_scan only reads (on, the
-   default), or by k_scan in its pass (off).  A measurement and test knob: results never depend on it.            */
-int  sb_set_fill_in_strip(sb_ctx *ctx, int on);
 /* A band step (sb_band_seabreeze_diag_*_dev, or a diag call with gathered moments in use) on the strip kernel runs
    k_scan and k_wind ahead of the join with the communication stream and lets the contrast kernel apply the update
    (0, the default), or k_scan | join | contrast kernel, k_wind -- the three kernels of a single-domain call, one

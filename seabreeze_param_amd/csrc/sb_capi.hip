@@ -134,7 +134,6 @@ struct sb_ctx {
     int host_depth = 0;                 // > 0 inside a host-pointer entry point: staged copies have no identity
     int no_fold = 0;                    // sb_set_fold(ctx, 0): k_prep stays a kernel of its own
     int no_plan_cache = 0;              // sb_set_plan_cache(ctx, 0): the strip kernel plans its march afresh every call
-    int no_strip_fill = 0;              // sb_set_fill_in_strip(ctx, 0): k_scan writes the fill value outside the band itself
     int no_wide_strip = 0;              // sb_set_wide_strip(ctx, 0): radii beyond 16 take the tile kernel in single precision too
     int band_late_wind = 0;             // sb_set_band_order(ctx, 1): a band step runs the contrast before k_wind (measurement)
     const void *stats_sigma = nullptr;
@@ -401,8 +400,6 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     job.gath = nullptr; job.ngath = 0;
     int launched = 0;
     lc.launches = &launched;
-    lc.strip_fills = !c->no_strip_fill;
-    job.strip_fills = 0;
     if (phases == 3) c->rep_launches = c->rep_rccl = c->rep_groups = c->rep_copies = 0;   // a band step resets them itself
     {
         const hipError_t le = sb_launch_diag<T>(job, Hk, lc);
@@ -1713,12 +1710,6 @@ int sb_set_band_order(sb_ctx *c, int contrast_first) {
 int sb_set_plan_cache(sb_ctx *c, int on) {
     if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
     c->no_plan_cache = on ? 0 : 1;
-    return SB_OK;
-}
-
-int sb_set_fill_in_strip(sb_ctx *c, int on) {
-    if (!c) return fail(nullptr, SB_ERR_ARG, "null context");
-    c->no_strip_fill = on ? 0 : 1;
     return SB_OK;
 }
 

@@ -310,7 +310,6 @@ struct DiagJob {
     const Moments *gath;            // band step: the moments gathered from every rank (ngath of them), merged by the first wave
     int ngath;                      //   of every k_thc3 workgroup in k_merge_moments' tree; 0: the scalars in stats stand
     int fold;
-    int strip_fills;                // the strip kernel writes the fill value outside the band behind its march (k_scan did not)
     int lists_stand;                // the segment lists of an earlier call are in place and belong to the planes the stored plan
                                     // belongs to: a march by that plan does not compact them again
     const Moments *fold_partials;   // k_scan's per-workgroup moments (fold_nparts of them; 0: the scalars in stats stand)

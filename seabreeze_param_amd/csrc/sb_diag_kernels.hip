@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256) void k_sigmoid_apply(const T *__restrict__ ary
 //            -> flag of the k_thc tile(s) the segment's band cells fall in
 //            -> fill value outside the band           ref :176 / seabreeze_diag_python.f90:173,279-280
 // ------------------------------------------------------------------------------------
-template <typename T, int SPT, bool WR, bool ST, bool FILL>      // WR: f2py flavour; ST: accumulate sigma's moments; FILL: write the fill value
+template <typename T, int SPT, bool WR, bool ST>      // WR: f2py flavour; ST: accumulate sigma's moments
 __global__ __launch_bounds__(STATS_NT) void k_scan(DiagJob<T> job, Moments *__restrict__ partials) {
     constexpr bool do_stats = ST;
     Moments t;
-    const bool plane_changed = sb_scan_pass<T, SPT, WR, ST, FILL>(job, t);
+    const bool plane_changed = sb_scan_pass<T, SPT, WR, ST>(job, t);
     const Geo g = job.g;
     const double c = do_stats ? (double)job.sigma[(size_t)g.h * g.nxh + g.h] : 0.0;
     if (plane_changed && job.plan_gen) atomicMax(job.plan_gen, job.call_id);
@@ -563,14 +563,12 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
 // k_scan is instantiated per flavour and with/without the statistics, so that neither is a branch in its
 // (issue-bound) segment loop
 template <typename T>
-static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool stats, hipStream_t st, bool fill = true) {
+static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool stats, hipStream_t st) {
     const bool wr = job.flavour == SB_FLAVOUR_WRAPPER;
-    if (wr && stats) hipLaunchKernelGGL((k_scan<T, 2, true, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (wr) hipLaunchKernelGGL((k_scan<T, 2, true, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (stats && fill) hipLaunchKernelGGL((k_scan<T, 2, false, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (stats) hipLaunchKernelGGL((k_scan<T, 2, false, true, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (fill) hipLaunchKernelGGL((k_scan<T, 2, false, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else hipLaunchKernelGGL((k_scan<T, 2, false, false, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    if (wr && stats) hipLaunchKernelGGL((k_scan<T, 2, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (wr) hipLaunchKernelGGL((k_scan<T, 2, true, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (stats) hipLaunchKernelGGL((k_scan<T, 2, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else hipLaunchKernelGGL((k_scan<T, 2, false, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
 }
 
 template <typename T>
@@ -612,21 +610,13 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
     // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there the contrast
     // kernel applies them.
     if (job.wind_final && ph1 && ph2 && !gathered) {
-        // host-model flavour on a strip kernel: it does k_prep's work itself (one dependent launch less on the critical
-        // path) -- and writes the fill value outside the band behind its march, so that k_scan only reads (lc.strip_fills)
-        const bool folds = job.strip && job.t0_fly && !lc.no_fold && nblk <= 1024;
-        const bool strip_fills = folds && lc.strip_fills && job.flavour == SB_FLAVOUR_GENERIC;
         SB_EV_BEGIN(SB_PROF_SCAN);
-        {
-            DiagJob<T> sj = job;                         // (k_scan leaves this copy in device memory: the strip kernel's tail reads it)
-            sj.strip_fills = strip_fills ? 1 : 0;
-            launch_scan<T>(sj, nblk, lc.partials, !reuse, st, !strip_fills);
-        }
+        launch_scan<T>(job, nblk, lc.partials, !reuse, st);
         SB_EV_END(SB_PROF_SCAN);
-        if (folds) {
+        // host-model flavour: the strip kernel does k_prep's work itself (one dependent launch less on the critical path)
+        if (job.strip && job.t0_fly && !lc.no_fold && nblk <= 1024) {
             DiagJob<T> fj = job;
             fj.fold = 1;
-            fj.strip_fills = strip_fills ? 1 : 0;
             fj.fold_partials = lc.partials;
             fj.fold_nparts = reuse ? 0 : nblk;
             fj.stats_out = (T *)lc.stats;

@@ -37,8 +37,6 @@ struct SbLaunchCtx {
     bool segs_stand;                // band step on the strip kernel: the segment lists of the call before are in place
                                     // (same geometry; k_wind checks on the device that the planes did not change): no k_prep
     int *launches;                  // += kernels enqueued by the call, or nullptr
-    bool strip_fills;               // single-domain host-model calls on a strip kernel: the fill value outside the band is written
-                                    // behind the march, k_scan only reads (sb_set_fill_in_strip; on by default)
 };
 
 template <typename T>

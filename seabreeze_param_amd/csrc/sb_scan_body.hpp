@@ -12,10 +12,9 @@
 #define SB_EAGER_PLANES 0          // 1: every word of the planes is written every call (A/B, debugging)
 #endif
 
-// WR: f2py flavour; ST: accumulate sigma's moments; FILL: write the fill value outside the band (off where the strip
-// kernel writes it behind its march: this pass then only reads).  Returns this THREAD's shifted sums in `mine` and
-// whether this thread's wave saw a word of the planes change.
-template <typename T, int SPT, bool WR, bool ST, bool FILL = true>
+// WR: f2py flavour; ST: accumulate sigma's moments.  Returns this THREAD's shifted sums in `mine` and whether this
+// thread's wave saw a word of the planes change.
+template <typename T, int SPT, bool WR, bool ST>
 __device__ __forceinline__ bool sb_scan_pass(const DiagJob<T> &job, Moments &mine, unsigned kernarg_job_off = 0) {
     constexpr bool wrapper = WR, do_stats = ST;
     constexpr int SCAN_NT = SB_STATS_NT;
@@ -127,7 +126,7 @@ __device__ __forceinline__ bool sb_scan_pass(const DiagJob<T> &job, Moments &min
                     if (wb & m) job.tile_nnmax[(tA + lane) * job.tile_sx + (yi / job.thc_ty) * job.tile_sy + job.tile_off] = 1;   // benign duplicates
                 }
             }
-            if (FILL && interior && yi < g.rows && !band) {
+            if (interior && yi < g.rows && !band) {
                 const unsigned o = (unsigned)yi * unx + (unsigned)xi;
                 if (!wrapper) job.sb_con[o] = job.fill;     // (non-temporal stores measured the same: 118.0 against 118.6 us per call)
                 else {

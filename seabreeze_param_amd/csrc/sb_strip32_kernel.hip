@@ -842,34 +842,6 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
             if (tid == 0) job.seg_count[part] = total;
         }
     }
-    if (job.fold && job.cold->strip_fills) {             // (read from the job's copy in device memory: k_scan of this call wrote it)
-        // ---- the fill value outside the coastal band (ref: generic/sea_breeze_diag.f90:174-176), written HERE and not by
-        // k_scan (round 4): k_scan then only reads -- two streams in, none out -- and the 35 MB of stores go out while the
-        // memory system idles under the march.  Every workgroup takes an equal share of the 64-cell segments; a wave reads
-        // the band words of eight segments at a time and stores the value where a bit is clear.
-        T *const fill_to = job.cold->sb_con;
-        const T fill_value = job.cold->fill;
-        const unsigned nseg = (unsigned)g.nyh * (unsigned)g.nw, unw = (unsigned)g.nw;
-        const unsigned per = (nseg + (unsigned)G - 1u) / (unsigned)G;
-        const unsigned s0 = min((unsigned)blockIdx.x * per, nseg), s1 = min(s0 + per, nseg);
-        for (unsigned base = s0 + (unsigned)wv; base < s1; base += 8u * NWV) {
-            u64 w[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned seg = base + (unsigned)q * NWV;
-                w[q] = job.bandbits[seg < s1 ? seg : s0];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned seg = base + (unsigned)q * NWV;
-                if (seg >= s1) break;                        // wave-uniform
-                const unsigned Y = seg / unw, Xw = seg - Y * unw;
-                const int xi = (int)(Xw * 64u) + lane - g.h, yi = (int)Y - g.h;
-                if (xi >= 0 && xi < g.nx && yi >= 0 && yi < g.rows && !((w[q] >> lane) & 1ull))
-                    fill_to[(unsigned)yi * (unsigned)g.nx + (unsigned)xi] = fill_value;
-            }
-        }
-    }
     SB_T(7);                                             // end
 }
 

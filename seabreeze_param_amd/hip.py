@@ -135,10 +135,6 @@ class Context:
         """The strip kernel keeps its plan while the band plane stands (default) or plans every call (measurement / test knob)."""
         self._chk(self.lib.sb_set_plan_cache(self.h, C.c_int(1 if on else 0)), "sb_set_plan_cache")
 
-    def set_fill_in_strip(self, on: bool):
-        """The fill value outside the band written behind the strip kernel's march (default) or by k_scan (test knob)."""
-        self._chk(self.lib.sb_set_fill_in_strip(self.h, C.c_int(1 if on else 0)), "sb_set_fill_in_strip")
-
     def set_wide_strip(self, on: bool):
         """Radii beyond 16 in single precision: the 96-column strip kernel (default) or the tile kernel (test knob)."""
         self._chk(self.lib.sb_set_wide_strip(self.h, C.c_int(1 if on else 0)), "sb_set_wide_strip")

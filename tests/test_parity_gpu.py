@@ -279,11 +279,10 @@ def test_band_that_reaches_the_first_and_the_last_row(hipctx, oracles, nwg):
 
 @pytest.mark.parametrize("shape,hint,dt", [((256, 192), 16, np.float64), ((250, 190), 16, np.float64), ((1024, 768), 16, np.float64),
                                             ((250, 190), 30, np.float32), ((96, 72), 16, np.float32)])
-def test_fill_value_outside_the_band_whoever_writes_it(hipctx, oracles, shape, hint, dt):
-    """sb_con = 0.0 in every cell beyond maxdist, every call (ref: generic/sea_breeze_diag.f90:174-176): written by the
-    strip kernel behind its march (the default: k_scan then only reads) or by k_scan (sb_set_fill_in_strip(ctx, 0)).
-    Both must overwrite every such cell of a poisoned array -- ragged grids, both strip kernels -- leave every other array
-    alone there, and agree bit for bit everywhere."""
+def test_fill_value_outside_the_band(hipctx, oracles, shape, hint, dt):
+    """sb_con = 0.0 in every cell beyond maxdist, every call, and nothing else touched there (ref:
+    generic/sea_breeze_diag.f90:174-176): every such cell of a poisoned array is overwritten -- ragged grids, both strip
+    kernels -- and the state arrays keep their markers."""
     nx, ny = shape
     nz = 2
     orc = oracles[8]
@@ -296,27 +295,20 @@ def test_fill_value_outside_the_band_whoever_writes_it(hipctx, oracles, shape, h
     assert band.any() and (~band).any()
     p = synth.pressure_3d(st, nz, dt)
     hipctx.set_search_radius_hint(hint)
-    results = {}
     try:
-        for in_strip in (True, False):
-            hipctx.set_fill_in_strip(in_strip)
-            state = _states(ny, nx, dt, 4)
-            for tn in (1, 2, 3):
-                th = synth.theta_step(st, tn, dt)
-                u, v = synth.wind_step(st, nz, tn, dt)
-                state[3][:] = np.nan                                   # poison: every cell must be written
-                marker = dt(-123.5)
-                for a in state[:3]:
-                    a[~band] = marker                                  # ... and nothing else touched beyond the band
-                hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *state, halo=0, bnd=hip.SB_BND_GLOBAL)
-                assert np.all(state[3][~band] == 0.0) and not np.isnan(state[3]).any(), (in_strip, tn)
-                assert all(np.all(a[~band] == marker) for a in state[:3]), (in_strip, tn)
-            results[in_strip] = [a.copy() for a in state]
+        state = _states(ny, nx, dt, 4)
+        for tn in (1, 2, 3):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            state[3][:] = np.nan                                   # poison: every cell must be written
+            marker = dt(-123.5)
+            for a in state[:3]:
+                a[~band] = marker                                  # ... and nothing else touched beyond the band
+            hipctx.seabreeze_diag(7200.0, tn, p, u, v, th, cdist, st.z, st.sigma, *state, halo=0, bnd=hip.SB_BND_GLOBAL)
+            assert np.all(state[3][~band] == 0.0) and not np.isnan(state[3]).any(), tn
+            assert all(np.all(a[~band] == marker) for a in state[:3]), tn
     finally:
-        hipctx.set_fill_in_strip(True)
         hipctx.set_search_radius_hint(16)
-    for a, b in zip(results[True], results[False]):
-        assert np.array_equal(a, b)
 
 
 def test_alternating_grids_and_contrast_kernels_in_one_context(hipctx, oracles):
