@@ -163,6 +163,8 @@ def diag(tt, lsm, z, std, lon, lat, pres, *args, **kwargs):
                 and out_arr.flags.c_contiguous and out_arr.flags.writeable):
             raise ValueError(f"out= must be a writeable C-contiguous float64 array of shape {(nt, nlat, nlon)}")
         sb_all = out_arr
+        sb_all[:, -1, :] = 0.0                    # (the kernels leave the last latitude row alone, ref seabreeze_diag_python.f90:165:
+                                                  #  in a fresh result array it reads 0.0, so it does here)
     dist = None if ci is not None else _coast_distance(lsm, np.zeros_like(lsm), lon, lat)
 
     static_seen = [False]

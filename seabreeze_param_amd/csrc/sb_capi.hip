@@ -282,9 +282,10 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
     const int nflag = ntile + 2;
     if (c->tiles.cap < (size_t)2 * nflag * sizeof(int) || c->tiles_n != nflag || c->tiles_strip != (strip ? vb : 0)) {
         if ((rc = ensure(c, c->tiles, (size_t)2 * nflag * sizeof(int)))) return rc;
-        // (in stream order: a plain hipMemset runs on the null stream, which the non-blocking streams kernels are
-        // enqueued on do not wait for -- a late memset could wipe flags k_scan had already raised)
-        HIPCHK(c, hipDeviceSynchronize());
+        // (in stream order, on the call's own stream: a plain hipMemset runs on the null stream, which the non-blocking
+        // streams kernels are enqueued on do not wait for -- a late memset could wipe flags k_scan had already raised.  No
+        // device-wide synchronisation: what ran before on this stream is ordered before the memset, and a reallocation
+        // above has synchronised already)
         HIPCHK(c, hipMemsetAsync(c->tiles.p, 0, (size_t)2 * nflag * sizeof(int), st));
         c->tiles_n = nflag;
         c->tiles_strip = strip ? vb : 0;
@@ -347,15 +348,13 @@ int run_diag(sb_ctx *c, DiagJob<T> &job, hipStream_t st, int phases = 3) {
         const size_t need = 64 + (size_t)c->ncu * SB_PLAN_STRIDE;
         if (c->plan.cap < need) {
             if ((rc = ensure(c, c->plan, need))) return rc;
-            HIPCHK(c, hipDeviceSynchronize());
-            HIPCHK(c, hipMemsetAsync(c->plan.p, 0, need, st));   // no plan stored, no change seen
+            HIPCHK(c, hipMemsetAsync(c->plan.p, 0, need, st));   // no plan stored, no change seen (stream-ordered)
             c->plan_bits = nullptr;
         }
         if (phases & 1) {
             // a new call: its number, and whether the stored plan was made for this geometry, by this many workgroups,
             // from planes that live where this call's do
             if (c->call_seq == 0x7fffffff) {                 // (the numbers start over: nothing stored counts)
-                HIPCHK(c, hipDeviceSynchronize());
                 HIPCHK(c, hipMemsetAsync(c->plan.p, 0, need, st));
                 c->call_seq = 0;
                 c->plan_bits = nullptr;

@@ -562,13 +562,21 @@ hipError_t sb_launch_sigmoid_apply(const T *ary, T *sm, size_t n, const T *stats
 
 // k_scan is instantiated per flavour and with/without the statistics, so that neither is a branch in its
 // (issue-bound) segment loop
+// segments per trip of a wave of k_scan (two trips in flight): 2 in double precision; SB_SCAN_SPT_F32 in single precision,
+// where a segment is half the bytes
+#ifndef SB_SCAN_SPT_F32
+#define SB_SCAN_SPT_F32 4              // (measured: 5120x3840 fp32 k_scan 73 -> 61 us against 2; the same at 2560x1920)
+#endif
+template <typename T> struct SCAN_SPT { static constexpr int value = 2; };
+template <> struct SCAN_SPT<float> { static constexpr int value = SB_SCAN_SPT_F32; };
+
 template <typename T>
 static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool stats, hipStream_t st) {
     const bool wr = job.flavour == SB_FLAVOUR_WRAPPER;
-    if (wr && stats) hipLaunchKernelGGL((k_scan<T, 2, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (wr) hipLaunchKernelGGL((k_scan<T, 2, true, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else if (stats) hipLaunchKernelGGL((k_scan<T, 2, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
-    else hipLaunchKernelGGL((k_scan<T, 2, false, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    if (wr && stats) hipLaunchKernelGGL((k_scan<T, SCAN_SPT<T>::value, true, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (wr) hipLaunchKernelGGL((k_scan<T, SCAN_SPT<T>::value, true, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else if (stats) hipLaunchKernelGGL((k_scan<T, SCAN_SPT<T>::value, false, true>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
+    else hipLaunchKernelGGL((k_scan<T, SCAN_SPT<T>::value, false, false>), dim3(nblk), dim3(STATS_NT), 0, st, job, partials);
 }
 
 template <typename T>
