@@ -356,13 +356,24 @@ __global__ __launch_bounds__(256 * DIST_ROWS) void k_dist_bits(const uint64_t *_
     uint64_t rowmask;
     {
         const int lane = tx & 63, wx0 = x0 + (tx & ~63);
-        const bool seam = wx0 - k < 0 || wx0 + 63 + k >= nx;
         const int ys = yy + lane - k;
         uint64_t any = 0;
         if (rowok && lane <= 2 * k && ys >= 0 && ys < ny) {
-            if (seam) any = 1;
-            else
-                for (int w = (wx0 - k) >> 6; w <= (wx0 + 63 + k) >> 6; ++w) any |= bits[(size_t)ys * nw + w];
+            // (whole words: an over-estimate of the reach, never an under-estimate; a reach that crosses the seam is two
+            // pieces -- round 3 kept every row for such a wave, and one workgroup column in five of the N1280 grid did the
+            // whole walk over empty windows)
+            const uint64_t *rw = bits + (size_t)ys * nw;
+            int lo = wx0 - k, hi = wx0 + 63 + k;
+            hi = hi < nx + lo ? hi : nx + lo - 1;                // (at most once round the circle)
+            if (lo < 0) {
+                for (int w = (lo + nx) >> 6; w < nw; ++w) any |= rw[w];
+                lo = 0;
+            }
+            if (hi >= nx) {
+                for (int w = 0; w <= (hi - nx) >> 6; ++w) any |= rw[w];
+                hi = nx - 1;
+            }
+            for (int w = lo >> 6; w <= hi >> 6; ++w) any |= rw[w];
         }
         rowmask = __ballot(any != 0);
     }
