@@ -178,3 +178,59 @@ def test_double_precision_keeps_the_tile_kernel(wide, oracles):
         wide.seabreeze_diag(7200.0, tn, p, u, v, th, cd, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
     for a, b, nm in zip(sh, so, ("ws", "wd", "thc", "sb_con")):
         assert relerr(a, b, floor=1e-2) < 1e-7, nm
+
+
+@pytest.mark.parametrize("static_sigma", [False, True], ids=["default", "static-sigma"])
+def test_band_step_owning_the_globe(oracles, static_sigma):
+    """sb_band_seabreeze_diag_f32_dev with a ghost frame of 30 cells: the 96-column kernel merges the gathered moments,
+    takes theta's east-west ghost columns and the rows beyond the poles by index arithmetic and applies the update behind
+    its march; several steps against the single-domain oracle under the shared single-precision rule."""
+    import torch
+    orc8 = oracles[8]
+    nx, ny, nz, h = 256, 192, 2, 30
+    dt = np.float32
+    st, cd = _case(orc8, nx, ny, kwin=27)
+    p = synth.pressure_3d(st, nz, dt)
+    ctx = hip.Context(0)
+    try:
+        ctx.set_search_radius_hint(h)
+        ctx.set_static_sigma(static_sigma)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def frame(a):
+            f = torch.zeros((ny + 2 * h, nx + 2 * h), dtype=torch.float32, device="cuda")
+            f[h:h + ny, h:h + nx] = torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+            torch.cuda.synchronize()
+            return f
+
+        def static(a):
+            f = frame(a)
+            ctx.swap_bounds_dev(dt, f.data_ptr(), nx, ny, h, stream)
+            ctx.synchronize()
+            return f
+
+        z, sg, mk = static(st.z), static(st.sigma), static(cd)
+        pd = torch.from_numpy(p).cuda()
+        state = [torch.zeros((ny, nx), dtype=torch.float32, device="cuda") for _ in range(4)]
+        so = [np.zeros((ny, nx), np.float64) for _ in range(4)]
+        band = np.abs(f8(cd)) <= 180.0
+        per, launches = [], []
+        for tn in (1, 2, 3, 4):
+            th = synth.theta_step(st, tn, dt)
+            u, v = synth.wind_step(st, nz, tn, dt)
+            thf, ud, vd = frame(th), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+            gp, op = [s.cpu().numpy() for s in state], [a.copy() for a in so]
+            torch.cuda.synchronize()
+            ctx.band_seabreeze_diag_dev(dt, 7200.0, tn, nx, ny, nz, h, pd.data_ptr(), ud.data_ptr(), vd.data_ptr(),
+                                        thf.data_ptr(), mk.data_ptr(), z.data_ptr(), sg.data_ptr(),
+                                        *[s.data_ptr() for s in state], stream)
+            ctx.synchronize()
+            launches.append(ctx.last_step_report()["kernel_launches"])
+            orc8.seabreeze_diag(7200.0, tn, f8(p), f8(u), f8(v), f8(th), f8(cd), f8(st.z), f8(st.sigma), *so, halo=0, bnd=1)
+            per.append(crit.check_step(tn, gp, [s.cpu().numpy() for s in state], op, so, band, timestep=7200.0))
+        res = crit.merge(per)
+        assert res["ok"], res
+        assert orc8.last_nn_max > 16 and ctx.last_counters()["global_path_cells"] == 0
+        assert launches == [4, 3, 3, 3], launches            # k_prep in the first step only, no ghost-fill kernel
+    finally:
+        ctx.close()
