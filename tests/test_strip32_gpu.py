@@ -234,3 +234,36 @@ def test_band_step_owning_the_globe(oracles, static_sigma):
         assert launches == [4, 3, 3, 3], launches            # k_prep in the first step only, no ghost-fill kernel
     finally:
         ctx.close()
+
+
+def test_stored_plan_follows_the_planes(wide, oracles):
+    """The 96-column kernel marches by the plan an earlier call stored while k_scan finds both planes unchanged: calls
+    that repeat the coast distance, shift its band, flip its sign (same band, other classes, radii beyond 31 among
+    them) and come back all match the oracle, call by call -- with the winds and the state carried through."""
+    orc8 = oracles[8]
+    nx, ny, nz = 256, 192, 2
+    dt = np.float32
+    st, base = _case(orc8, nx, ny, kwin=27)
+    coast = orc8.get_edges(f8(st.landfrac), f8(st.icefrac))
+    far = orc8.get_dist(coast, f8(st.landfrac), st.lon, st.lat, maxdist=700.0)
+    flipped = np.where(np.abs(far) < 12000.0, -far, far)       # (as in test_radii_beyond_31_take_the_global_path)
+    flipped[np.abs(flipped) > 180.0] = 12000.0
+    flipped = flipped.astype(dt)
+    rolled = np.roll(base, 7, axis=1)
+    p = synth.pressure_3d(st, nz, dt)
+    sh = [np.zeros((ny, nx), dt) for _ in range(4)]
+    so = [np.zeros((ny, nx), np.float64) for _ in range(4)]
+    marked = []
+    for tn, cd in enumerate((base, base, rolled, rolled, flipped, flipped, base, base), start=1):
+        th = synth.theta_step(st, tn, dt)
+        u, v = synth.wind_step(st, nz, tn, dt)
+        gp, op = [a.copy() for a in sh], [a.copy() for a in so]
+        orc8.seabreeze_diag(7200.0, tn, f8(p), f8(u), f8(v), f8(th), f8(cd), f8(st.z), f8(st.sigma), *so, halo=0, bnd=1)
+        wide.seabreeze_diag(7200.0, tn, p, u, v, th, cd, st.z, st.sigma, *sh, halo=0, bnd=hip.SB_BND_GLOBAL)
+        res = crit.merge([crit.check_step(tn, gp, sh, op, so, np.abs(f8(cd)) <= 180.0, timestep=7200.0)])
+        assert res["ok"], (tn, res)
+        c = wide.last_counters()
+        assert c["max_radius"] == orc8.last_nn_max, (tn, c, orc8.last_nn_max)
+        marked.append(c["global_path_cells"])
+    assert marked[0] == marked[1] == marked[2] == marked[3] == marked[6] == marked[7] == 0, marked
+    assert marked[4] > 0 and marked[4] == marked[5], marked       # the stored plan names the same marked cells
