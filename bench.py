@@ -249,6 +249,29 @@ def time_setup_kernels(ctx, torch, st, coast, dt, kwin, reps=5):
     return res
 
 
+class Watchdog:
+    """N > 1 only: a rank that passes no stage mark for `limit` seconds (a collective some other rank never joined, a
+    transport that never connects) says where it stands and ends its process with exit code 5 -- the launcher then
+    tears the job down instead of waiting for ever.  The multi-rank RCCL path has not run on hardware yet."""
+
+    def __init__(self, limit, rank):
+        import threading
+        self.limit, self.rank, self.stage, self.t = limit, rank, "start", time.monotonic()
+        if limit > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def mark(self, stage):
+        self.stage, self.t = stage, time.monotonic()
+
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            if time.monotonic() - self.t > self.limit:
+                print(f"[bench rank {self.rank}] no progress for {self.limit:.0f} s in stage '{self.stage}': giving up",
+                      file=sys.stderr, flush=True)
+                os._exit(5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +295,8 @@ def main():
     ap.add_argument("--no-replan", action="store_true",
                     help="skip the extra passes with sb_set_plan_cache(ctx, 0) (profiling runs: rocprofv3's per-kernel averages "
                          "then refer to the stored-plan state alone)")
+    ap.add_argument("--watchdog", type=float, default=600.0,
+                    help="N>1: seconds a rank may spend in one stage of the run before it gives up (0: never)")
     ap.add_argument("--static-sigma", action="store_true",
                     help="opt-in variant, never the headline: sigma's statistics formed once (sb_set_static_sigma)")
     args = ap.parse_args()
@@ -295,6 +320,7 @@ def main():
     # goes to one explicit stream (torch's default stream has handle 0, which the C ABI reads as "the context's own")
     torch.cuda.set_stream(torch.cuda.Stream())
     comm = args.comm
+    dog = Watchdog(args.watchdog if world > 1 else 0.0, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if comm in ("native", "gloo"):
@@ -341,6 +367,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             raise SystemExit(3)
+    dog.mark("setup chain and synthetic inputs")
     coast = ctx.get_edges(st.landfrac, st.icefrac)                    # HIP (product) setup chain
     cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
     kwin = hip.dist_window(st.lon, st.lat)
@@ -357,6 +384,7 @@ def main():
     u_full, v_full = synth.wind_step(st, nz, 1, dt, rows=rows)
     gen_s = time.perf_counter() - t_gen
 
+    dog.mark("uploads")
     runner = BandRunner(ctx, torch, dist if world > 1 else None, rank, world, nx, ny, nz, halo=kwin + 1, dtype=dt,
                         comm=comm if world > 1 else "torch", rows=rows, static_sigma=args.static_sigma)
     runner.upload_static(st.z, st.sigma, cdist)
@@ -378,6 +406,7 @@ def main():
 
     # ---- parity sequence (single GPU): tn = 1, 2, 15 from a zero state, states kept for the checker ----
     gpu_states = None
+    dog.mark("parity steps (first band steps: ghost rows and moments travel)")
     if not args.no_cpu_baseline:
         gpu_states = {"steps": [], "states": []}
         for tn in (1, 2, 15):
@@ -386,6 +415,7 @@ def main():
             gpu_states["steps"].append((tn, host_sets[tn % NSET]) if world == 1 else (tn, tn % NSET))
             gpu_states["states"].append([t.cpu().numpy().copy() for t in (runner.ws, runner.wd, runner.thc, runner.sb_con)])
     band_check = None
+    dog.mark("band parity against the oracle")
     if world > 1 and gpu_states is not None:
         # N > 1: every rank checks its own band (a serial oracle call on 1/N of the grid), the worst error travels to rank 0
         worst, flips = band_parity(st, cdist, rows, runner.h, host_sets, gpu_states, timestep, esz)
@@ -414,6 +444,7 @@ def main():
 
     events_inside = args.profile_passes == 0
     tn = 1
+    dog.mark("warm-up and timed steps")
     if events_inside:                                   # (the PMC passes: events of the K timed steps only)
         for _ in range(W):
             runner.step(timestep, tn, sets[tn % NSET]); tn += 1
@@ -426,6 +457,7 @@ def main():
     # ---- per-step HIP-event times (median): a K-step pass of its own; only where torch's events sit
     # on the stream the kernels run on (one HIP runtime) ---------------------------------------------------------
     median_ms = None
+    dog.mark("event passes")
     if shared_runtime:
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         evs[0].record()
@@ -458,6 +490,7 @@ def main():
         replan = {"ms_per_step": el_r / K * 1e3, "k_thc": round(kr["k_thc"], 5), "steps": K,
                   "what": "sb_set_plan_cache(ctx, 0): shares, schedule, cell lists, radius search in every call"}
 
+    dog.mark("report")
     ms_per_step = elapsed / K * 1e3
     value = nx * ny / (elapsed / K)
 

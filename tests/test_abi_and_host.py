@@ -144,3 +144,18 @@ def test_split_rows_properties():
         assert sp == bands.split_rows(ny, world, cost=cost.copy(), min_rows=min_rows)
 
     check()
+
+
+def test_bench_watchdog_ends_a_stalled_rank():
+    """bench.py, N > 1: a rank that passes no stage mark within the limit reports its stage and exits with code 5 (the
+    multi-rank RCCL exchange has never run on hardware: a hang must not hold the launcher for ever)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import bench, time; d = bench.Watchdog(1.0, 3); d.mark('ghost rows'); time.sleep(20)"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 5, (r.returncode, r.stderr[-400:])
+    assert "rank 3" in r.stderr and "ghost rows" in r.stderr
+    code = "import bench, time; d = bench.Watchdog(0.0, 0); time.sleep(2.5); print('alive')"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "alive" in r.stdout
