@@ -416,8 +416,11 @@ __device__ __forceinline__ T sb_ld(const T *p) {
 
 // MODE 0: the winds go to scratch planes (a band step, ahead of the contrast kernel, which applies the update);
 // 1: the update is applied here (single domain: the contrast kernel ran first)
+template <typename T> struct WindCfg { static constexpr int UN = SB_WIND_UN, WGS = SB_WIND_WGS_PER_CU; };
+template <> struct WindCfg<float> { static constexpr int UN = SB_WIND_UN_F32, WGS = SB_WIND_WGS_PER_CU_F32; };
+
 template <typename T, int UN, int MODE>
-__global__ __launch_bounds__(WIND_NT, SB_WIND_WGS_PER_CU) void k_wind(DiagJob<T> job) {
+__global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> job) {
     constexpr bool FINAL = MODE != 0;
     const Geo g = job.g;
     const int lane = threadIdx.x & 63;
@@ -581,9 +584,9 @@ static void launch_scan(const DiagJob<T> &job, int nblk, Moments *partials, bool
 
 template <typename T>
 static void launch_wind(const DiagJob<T> &job, int ncu, hipStream_t st) {
-    const dim3 wg(ncu * SB_WIND_WGS_PER_CU), wb(WIND_NT);
-    if (job.wind_final) hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 1>), wg, wb, 0, st, job);
-    else hipLaunchKernelGGL((k_wind<T, SB_WIND_UN, 0>), wg, wb, 0, st, job);
+    const dim3 wg(ncu * WindCfg<T>::WGS), wb(WIND_NT);
+    if (job.wind_final) hipLaunchKernelGGL((k_wind<T, WindCfg<T>::UN, 1>), wg, wb, 0, st, job);
+    else hipLaunchKernelGGL((k_wind<T, WindCfg<T>::UN, 0>), wg, wb, 0, st, job);
 }
 
 // event pair k of a profiled call brackets kernel k (SB_PROF_*); pairs of kernels a call does not launch stay unrecorded
@@ -613,6 +616,8 @@ hipError_t sb_launch_diag(const DiagJob<T> &job, int H, const SbLaunchCtx &lc) {
                                                                  // dependent trips -- k_scan is latency, not bytes, there
     if (nblk < 1) nblk = 1;
     if (nblk > lc.ncu) nblk = lc.ncu;                            // one 1024-thread workgroup per CU, two trips of loads in flight
+                                                                 // (two workgroups per CU, 8 waves per SIMD, measured slower in round 4:
+                                                                 // k_scan 25.0 -> 28.7 us at 2560x1920 fp64, 60.1 -> 65.0 at 5120x3840 fp32)
     const dim3 pg(2 + SB_SEG_PARTS), pb(PREP_NT);
     // Single-domain calls run the contrast first and let k_wind apply the thresholds and the state update
     // (job.wind_final); a band step must run k_scan + k_wind before its ghost rows arrive, so there the contrast

@@ -16,6 +16,12 @@ enum { SB_PROF_SCAN = 0, SB_PROF_WIND = 1, SB_PROF_T0 = 2, SB_PROF_THC = 3, SB_P
                                     // the gather is bound by the memory system from two workgroups per CU upwards,
                                     // tools/probe_gather.hip, and 128 registers keep the update code free of spills)
 #endif
+#ifndef SB_WIND_UN_F32
+#define SB_WIND_UN_F32 14           // ... and the two constants in single precision: a load brings half the bytes, so a wave
+#endif                              // keeps more of them in flight and the update's registers (57) allow eight waves per SIMD.
+#ifndef SB_WIND_WGS_PER_CU_F32      // Measured on one box (k_wind, 5120x3840x56 fp32): 8 loads x 4 workgroups 138.6 us,
+#define SB_WIND_WGS_PER_CU_F32 8    // 16 x 4 131.8, 16 x 6 126.4, 8 x 8 120.3, 14 x 7 119.1, 19 x 8 117.6, 28 x 8 118.1,
+#endif                              // 14 x 8 114.3-118.1; 2560x1920x56 fp32: 50.1 -> 39.7 us
 
 // Everything of the context a diag launch needs besides the job itself.
 struct SbLaunchCtx {
