@@ -366,8 +366,10 @@ __host__ __device__ inline T sb_modulo(T a, T p) {
 }
 
 // 1/(1+exp(y)) in the working precision.  For doubles: exp by argument reduction to |r| <= ln2/2 (two-part ln2,
-// fused), a degree-11 Taylor polynomial and v_ldexp_f64; the reciprocal by v_rcp_f64 and a Newton step.  About 30
+// fused), a degree-11 Taylor polynomial and v_ldexp_f64; the reciprocal by v_rcp_f64 and two Newton steps.  About 30
 // instructions against about 90 for libm's exp plus an IEEE division, and within a few ulp of them.
+// ONE evaluation order for every kernel (the strip kernel's copy, strip_logistic_of_neg, differs only in where its
+// constants come from): t0 is the same to the last bit whichever kernel forms it.
 template <typename T>
 __device__ __forceinline__ T sb_logistic_of_neg(T y) {        // returns 1 / (1 + exp(y))
     return T(1) / (T(1) + exp(y));
@@ -378,20 +380,21 @@ __device__ __forceinline__ double sb_logistic_of_neg<double>(double y) {
     const double n = __builtin_rint(y * 1.4426950408889634);
     double r = __builtin_fma(-n, 0.6931471805599453, y);
     r = __builtin_fma(-n, 2.3190468138462996e-17, r);         // |r| <= ln2/2
-    // exp(r) by its Taylor polynomial of degree 11 (truncation r^12/12! < 7e-15 relative), evaluated in Estrin's
-    // scheme: the kernels that call this are bound by the latency of their dependent chains, not by instruction
-    // issue, and the tree is 5 fused multiply-adds deep where Horner's rule is 11
-    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
-    const double p01 = __builtin_fma(r, 1.0, 1.0);
-    const double p23 = __builtin_fma(r, 1.6666666666666666e-01, 0.5);
-    const double p45 = __builtin_fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
-    const double p67 = __builtin_fma(r, 1.984126984126984e-04, 1.388888888888889e-03);
-    const double p89 = __builtin_fma(r, 2.7557319223985893e-06, 2.48015873015873e-05);
-    const double pab = __builtin_fma(r, 2.505210838544172e-08, 2.755731922398589e-07);
-    const double q0 = __builtin_fma(r2, p23, p01), q1 = __builtin_fma(r2, p67, p45), q2 = __builtin_fma(r2, pab, p89);
-    const double p = __builtin_fma(r8, q2, __builtin_fma(r4, q1, q0));
+    // exp(r) by its Taylor polynomial of degree 11 (truncation r^12/12! < 7e-15 relative) as E(r^2) + r O(r^2): two
+    // independent Horner chains of five fused multiply-adds (six deep in all, where one chain would be eleven)
+    const double r2 = r * r;
+    double e = __builtin_fma(r2, 2.755731922398589e-07, 2.48015873015873e-05);               // 1/10!, 1/8!
+    double o = __builtin_fma(r2, 2.505210838544172e-08, 2.7557319223985893e-06);             // 1/11!, 1/9!
+    e = __builtin_fma(e, r2, 1.388888888888889e-03);   o = __builtin_fma(o, r2, 1.984126984126984e-04);      // 1/6!, 1/7!
+    e = __builtin_fma(e, r2, 4.1666666666666664e-02);  o = __builtin_fma(o, r2, 8.333333333333333e-03);      // 1/4!, 1/5!
+    e = __builtin_fma(e, r2, 0.5);                     o = __builtin_fma(o, r2, 1.6666666666666666e-01);      // 1/2!, 1/3!
+    e = __builtin_fma(e, r2, 1.0);                     o = __builtin_fma(o, r2, 1.0);
+    const double p = __builtin_fma(o, r, e);
     const double x = 1.0 + ldexp(p, (int)n);
-    double q = __builtin_amdgcn_rcp(x);                       // v_rcp_f64 and one Newton step: relative error < 1e-15
+    // v_rcp_f64 is good to about 2^-24 relative (2^29 ulp); a Newton step squares the error: 4e-15 after one, rounding
+    // level after two
+    double q = __builtin_amdgcn_rcp(x);
+    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
     q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
     return q;
 }

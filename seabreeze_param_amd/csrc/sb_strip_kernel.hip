@@ -85,7 +85,8 @@ typedef const __attribute__((address_space(4))) double *sb_cdp;
 #define SB_K(i, lit) (lit)
 #endif
 
-// 1 / (1 + exp(y)): as sb_logistic_of_neg<double> (sb_device.hpp), constants from the table
+// 1 / (1 + exp(y)): sb_logistic_of_neg<double> (sb_device.hpp) operation for operation -- the same bits --, its
+// constants optionally from the table
 __device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
     y = fmin(fmax(y, -708.0), 700.0);                         // (literals: known not to be NaN, no canonicalisation)
     const double n = __builtin_rint(y * SB_K(0, 1.4426950408889634));
@@ -102,7 +103,8 @@ __device__ __forceinline__ double strip_logistic_of_neg(double y, sb_cdp k) {
     e = __builtin_fma(e, r2, 1.0);   o = __builtin_fma(o, r2, 1.0);
     const double p = __builtin_fma(o, r, e);
     const double x = 1.0 + ldexp(p, (int)n);
-    double q = __builtin_amdgcn_rcp(x);                       // v_rcp_f64 and one Newton step: relative error < 1e-15
+    double q = __builtin_amdgcn_rcp(x);                       // v_rcp_f64 (2^-24 relative) and two Newton steps, as sb_logistic_of_neg
+    q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
     q = __builtin_fma(q, __builtin_fma(-x, q, 1.0), q);
     return q;
 }
