@@ -81,8 +81,11 @@ const char *sb_last_error(const sb_ctx *ctx);        /* ctx may be NULL         
 const char *sb_version(void);
 void sb_default_tunables(sb_tunables *t);
 /* Expected largest search radius of the land/sea window: up to 16 the marching-strip contrast
-   kernel runs (LDS halo 16), beyond it the tile kernel with a halo of 24 or 32 cells; results never
-   depend on it -- cells that need more take a global-memory path.                    */
+   kernel runs (LDS halo 16); beyond it, in single precision, the 96-column strip kernel (radii up to 31 from LDS),
+   in double precision the tile kernel with a halo of 24 or 32 cells.  Correctness never depends on it -- cells that
+   need more take a global-memory path --, and t0 is formed by one sequence of operations in every kernel; the window
+   means are exact fixed-point sums in the strip kernels and rounded sums in the tile kernel and on the global path,
+   so thc may differ between kernels in its last bits (fp64: a few ulp; the tests hold 1e-7 against the reference). */
 int  sb_set_search_radius_hint(sb_ctx *ctx, int radius);
 /* Single-domain host-model calls let the strip contrast kernel merge k_scan's statistics and compact
    k_wind's segment lists itself (on, the default) or leave that to a kernel of its own between k_scan and
