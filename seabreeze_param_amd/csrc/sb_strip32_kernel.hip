@@ -136,6 +136,8 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
     typedef const __attribute__((address_space(4))) int *cintp;
     char *const plan_wg = plan + (size_t)blockIdx.x * SB_PLAN_STRIDE;
     unsigned *const plan_lists = (unsigned *)(plan_wg + SB_PLAN_LIST_OFF);
+    // (the stored plan's steps travel WITH its header -- one round trip, not two; used only if the plan stands)
+    const uint2 plan_ent = ((const uint2 *)(plan_wg + SB_PLAN_ENT_OFF))[tid < S32_SCHED ? tid : 0];
     const int plan_stored = ((cintp)plan_wg)[0], plan_nst = min(((cintp)plan_wg)[1], S32_SCHED);
     const int plan_rb = ((cintp)plan_wg)[2], plan_re = ((cintp)plan_wg)[3];
     const bool cached = job.plan_use != 0 && plan_stored != 0 && *(cintp)plan_gen <= plan_stored;      // uniform
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
     };
     if (!cached) load_plane();
     else {
-        if (tid < plan_nst) s_ent[tid] = ((const uint2 *)(plan_wg + SB_PLAN_ENT_OFF))[tid];      // (at most S32_SCHED < 1024 steps)
+        if (tid < plan_nst) s_ent[tid] = plan_ent;      // (at most S32_SCHED < 1024 steps)
         if (tid == 0) { s_misc[0] = plan_nst; s_misc[5] = plan_rb; s_misc[6] = plan_re; s_misc[8] = 0; }
     }
     if (tid == 0) s_misc[4] = 0;

@@ -16,6 +16,8 @@ nx, ny, nz = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (2560, 1
 dt = np.float64
 st = synth.static_fields(nx, ny, dt)
 ctx = hip.Context()
+if len(sys.argv) > 4 and sys.argv[4] == "replan":     # the planning call's path: no stored plan
+    ctx.set_plan_cache(False)
 coast = ctx.get_edges(st.landfrac, st.icefrac)
 cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
 p = synth.pressure_3d(st, nz, dt)
