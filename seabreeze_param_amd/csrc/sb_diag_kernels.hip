@@ -419,11 +419,26 @@ __device__ __forceinline__ T sb_ld(const T *p) {
 template <typename T> struct WindCfg { static constexpr int UN = SB_WIND_UN, WGS = SB_WIND_WGS_PER_CU; };
 template <> struct WindCfg<float> { static constexpr int UN = SB_WIND_UN_F32, WGS = SB_WIND_WGS_PER_CU_F32; };
 
+// diagnostic build (make stamps EXTRA=-DSB_STAMPS_WIND, tools/stamp_wind.py): the wall clock of every wave of k_wind at
+// the marks below (the strip kernels' marks are off in that build: one buffer)
+#ifdef SB_STAMPS_WIND
+#define SB_WT(i) do { if (stl_ && job.stamps) job.stamps[(size_t)gw_ * SB_NSTAMP + (i)] = wall_clock64(); } while (0)
+#else
+#define SB_WT(i) do { } while (0)
+#endif
+
 template <typename T, int UN, int MODE>
 __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> job) {
     constexpr bool FINAL = MODE != 0;
     const Geo g = job.g;
     const int lane = threadIdx.x & 63;
+#ifdef SB_STAMPS_WIND
+    const int gw_ = blockIdx.x * (WIND_NT / SB_WAVE) + (threadIdx.x >> 6);
+    int nsegs_ = 0;
+    bool stl_ = lane == 0;
+    if (gw_ < 4096 && lane < SB_NSTAMP && job.stamps) job.stamps[(size_t)gw_ * SB_NSTAMP + lane] = 0;
+#endif
+    SB_WT(0);                                            // start
     // clear the other tile-flag buffer for the next call (this call's was read by k_prep)
     for (int i = blockIdx.x * WIND_NT + threadIdx.x; i < job.next_flags_n; i += gridDim.x * WIND_NT) job.next_flags[i] = 0;
     // the sub-lists' sizes -> position of an entry: lane k holds (count, inclusive prefix) of sub-list k
@@ -451,6 +466,12 @@ __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> jo
     }
     // one aligned 64-cell segment: its band lanes walk their column
     auto segment = [&](const SbSegEntry cur) __attribute__((always_inline)) {
+#ifdef SB_STAMPS_WIND
+        const int sbase_ = 3 + 4 * (nsegs_ < 6 ? nsegs_ : 6);
+        ++nsegs_;
+        stl_ = lane == __ffsll((unsigned long long)cur.word) - 1;     // the segment's first band lane keeps the clock
+        SB_WT(sbase_);                                   // segment begins (its entry has arrived)
+#endif
         const unsigned Y = cur.seg / (unsigned)g.nw, Xw = cur.seg - Y * (unsigned)g.nw;
         const int x = (int)(Xw * 64u) + lane - g.h, y = (int)Y - g.h;
         if (!((cur.word >> lane) & 1ull)) return;               // band bits are set for interior cells of processed rows only
@@ -506,8 +527,16 @@ __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> jo
                 }
             }
         }
+#ifdef SB_STAMPS_WIND
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SB_WT(sbase_ + 1);                               // column walked
+#endif
         const T uu = job.u[(size_t)lev * pl + o];
         const T vv = job.v[(size_t)lev * pl + o];
+#ifdef SB_STAMPS_WIND
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SB_WT(sbase_ + 2);                               // u, v there
+#endif
         const T n_ws = sqrt(uu * uu + vv * vv);                  // ref :225
         const T n_wd = atan2(-uu, -vv) * T(57.2957);             // ref :227, rad2deg (sic) :128
         if constexpr (FINAL) {
@@ -518,6 +547,10 @@ __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> jo
             job.nws[o] = n_ws;
             job.nwd[o] = n_wd;
         }
+#ifdef SB_STAMPS_WIND
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SB_WT(sbase_ + 3);                               // updated, stores drained
+#endif
     };
     // The lists of the call before (a band step whose planning of the march stands: no k_prep in this call) hold as long
     // as k_scan found both planes unchanged; if it did not -- once per change of the coast -- the waves take the
@@ -531,6 +564,7 @@ __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> jo
         }
         return;
     }
+    SB_WT(1);                                            // sub-lists' sizes there
     if (gw >= total) return;
     SbSegEntry ent = entry(gw);
     for (int e = gw; e < total; e += nwaves) {
@@ -538,6 +572,10 @@ __global__ __launch_bounds__(WIND_NT, WindCfg<T>::WGS) void k_wind(DiagJob<T> jo
         if (e + nwaves < total) ent = entry(e + nwaves);          // the next entry travels under this one's walk
         segment(cur);
     }
+#ifdef SB_STAMPS_WIND
+    stl_ = lane == 0;
+#endif
+    SB_WT(2);                                            // end
 }
 
 // ------------------------------------------------------------------------------------

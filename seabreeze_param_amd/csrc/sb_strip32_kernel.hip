@@ -41,7 +41,7 @@
 #define S32_DEPTH 3               // blocks of inputs in flight per wave
 #define S32_QOFF (S32_HB + 1)     // a block is queried in the step that stages the block this many positions down
 
-#ifdef SB_STAMPS
+#if defined(SB_STAMPS) && !defined(SB_STAMPS_WIND)
 #define SB_T(i) do { if (lane == 0) job.stamps[(size_t)(blockIdx.x * (S32_NT / SB_WAVE) + wv) * SB_NSTAMP + (i)] = wall_clock64(); } while (0)
 #else
 #define SB_T(i) do { } while (0)
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
         // The three register sets take turns as three copies of the step, as in k_strip.
         auto step = [&](S32Regs<FLY> &RA, S32Regs<FLY> &RB, unsigned &E, unsigned &J, const unsigned &En, int i, int buf) __attribute__((always_inline)) {
             const unsigned ent = E, sj = J;
-#ifdef SB_STAMPS
+#if defined(SB_STAMPS) && !defined(SB_STAMPS_WIND)
             if (i < SB_NSTAMP - 5) SB_T(5 + i);          // step i begins (i >= 3)
 #endif
             entry(i + S32_DEPTH, E, J);                  // (consumed by `issue` below: the read travels under S1)

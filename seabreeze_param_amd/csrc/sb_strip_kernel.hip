@@ -56,7 +56,7 @@
 // Diagnostic build (-DSB_STAMPS: `make stamps`, tools/stamp_strip.py): every wave leaves the 100 MHz wall clock at a few
 // marks -- one scalar clock read and one exec-masked store each, no registers held (an earlier version summed shader
 // clocks per phase in 32 registers per lane: the spills that caused distorted what it measured).
-#ifdef SB_STAMPS
+#if defined(SB_STAMPS) && !defined(SB_STAMPS_WIND)
 #define SB_T(i) do { if (lane == 0) job.stamps[(size_t)(blockIdx.x * (STRIP_NT / SB_WAVE) + wv) * SB_NSTAMP + (i)] = wall_clock64(); } while (0)
 #else
 #define SB_T(i) do { } while (0)
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         // of blocks i + 1 and i + 2 stay in flight.  The set just consumed receives the loads of block i + 3.
         auto step = [&](StripRegs<T, FLY> &R, unsigned &E, unsigned &J, const unsigned &En, int i, int buf) __attribute__((always_inline)) {
             const unsigned ent = E, sj = J;
-#ifdef SB_STAMPS
+#if defined(SB_STAMPS) && !defined(SB_STAMPS_WIND)
             if (i < SB_NSTAMP - 5) SB_T(5 + i);          // step i begins (i >= 3)
 #endif
             entry(i + STRIP_DEPTH, E, J);                // (consumed by `issue` below: the read travels under S1)
