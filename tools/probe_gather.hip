@@ -69,6 +69,38 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ p, si
     }
 }
 
+// a wave takes MS ADJACENT segments (neighbours along longitude: the same pages of every plane) and walks them together,
+// UN levels of each in flight: per level one page of the plane serves MS loads of the wave
+template <int UN, int MS>
+__global__ __launch_bounds__(256) void k_gather_adj(const double *__restrict__ p, size_t plane, int nz, int nseg, int act,
+                                                    int stride, int misalign, double *__restrict__ out) {
+    const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    const int lane = threadIdx.x & 63;
+    auto cell_of = [&](int s) { return (size_t)s * stride + (misalign ? (s * 7) % 16 : 0) + lane; };
+    for (int base = gw * MS; base < nseg; base += MS * nw) {
+        double best[MS];
+        int lev[MS];
+        size_t cell[MS];
+#pragma unroll
+        for (int j = 0; j < MS; ++j) { best[j] = 1e300; lev[j] = 0; cell[j] = cell_of(base + j < nseg ? base + j : nseg - 1); }
+        if (lane < act) {
+            for (int k0 = 0; k0 < nz; k0 += UN) {
+                double d[MS][UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q)
+#pragma unroll
+                    for (int j = 0; j < MS; ++j) d[j][q] = __builtin_nontemporal_load(p + cell[j] + (size_t)(k0 + q < nz ? k0 + q : nz - 1) * plane);
+#pragma unroll
+                for (int j = 0; j < MS; ++j)
+#pragma unroll
+                    for (int q = 0; q < UN; ++q) { const double a = fabs(d[j][q] - 70000.0); if (a < best[j]) { best[j] = a; lev[j] = k0 + q; } }
+            }
+#pragma unroll
+            for (int j = 0; j < MS; ++j) if (base + j < nseg) out[cell[j]] = best[j] + lev[j];
+        }
+    }
+}
+
 // k_scan-shaped stream: read a and b, write c where a lane-dependent predicate holds (90 % of the cells)
 __global__ __launch_bounds__(1024) void k_stream2in1out(const double *__restrict__ a, const double *__restrict__ b,
                                                         double *__restrict__ c, size_t n, int wr) {
@@ -147,6 +179,12 @@ int main() {
             const double l14 = timeit([&] { hipLaunchKernelGGL((k_gather<14, true>), g, b, 0, s1, p, plane, nz, c.nseg, c.act, c.stride, c.misalign, out); });
             printf("   %d WG/CU: cell-major un8 %.1f us (%.0f GB/s of lines)  un28 %.1f  un56 %.1f | level-major un8 %.1f (%.0f GB/s)  un14 %.1f\n",
                    wgs, t8, fetched / t8 / 1e3, t28, t56, l8, fetched / l8 / 1e3, l14);
+            const double a24 = timeit([&] { hipLaunchKernelGGL((k_gather_adj<4, 2>), g, b, 0, s1, p, plane, nz, c.nseg, c.act, c.stride, c.misalign, out); });
+            const double a44 = timeit([&] { hipLaunchKernelGGL((k_gather_adj<4, 4>), g, b, 0, s1, p, plane, nz, c.nseg, c.act, c.stride, c.misalign, out); });
+            const double a28 = timeit([&] { hipLaunchKernelGGL((k_gather_adj<2, 8>), g, b, 0, s1, p, plane, nz, c.nseg, c.act, c.stride, c.misalign, out); });
+            const double a82 = timeit([&] { hipLaunchKernelGGL((k_gather_adj<8, 2>), g, b, 0, s1, p, plane, nz, c.nseg, c.act, c.stride, c.misalign, out); });
+            printf("              adjacent segments walked together (levels x segments in flight): 4x2 %.1f us  4x4 %.1f (%.0f GB/s of lines)  2x8 %.1f  8x2 %.1f\n",
+                   a24, a44, fetched / a44 / 1e3, a28, a82);
         }
     }
     // k_scan-shaped stream
