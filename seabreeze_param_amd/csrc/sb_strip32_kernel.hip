@@ -161,7 +161,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
             if (lane == 0) s_bits[c * NWV + wv] = b;
         }
     };
-    if (!cached) load_plane();
+    if (__builtin_expect(!cached, 0)) load_plane();
     else {
         if (tid < plan_nst) s_ent[tid] = plan_ent;      // (at most S32_SCHED < 1024 steps)
         if (tid == 0) { s_misc[0] = plan_nst; s_misc[5] = plan_rb; s_misc[6] = plan_re; s_misc[8] = 0; }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
         if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, last_sj);
         if (lane == 0) s_misc[0] = n_pad;
     };
-    if (!cached) {
+    if (__builtin_expect(!cached, 0)) {
         if (wv == 0) {
             make_prefix(true);
             const int rb0 = act_before_cost((int)(((long long)blockIdx.x * tot_cost) / G));
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
             found = valid && nn != 0;
             nn = max(nn, 1);                             // (reads in bounds; the result is not used)
         }
-        if (!cached) {
+        if (__builtin_expect(!cached, 0)) {
             const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
             const int e = wv * SB_WAVE + lane;
             valid = e < ncell;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
             i11 = p1 + rc; i10 = p1 + (unsigned)left; i01 = p0 + rc; i00 = p0 + (unsigned)left;
             b1 = p1 + rb; b0 = p0 + rb;
         };
-        if (!cached) {
+        if (__builtin_expect(!cached, 0)) {
             int lim = S32_HMAX;
             if (limited) lim = min(lim, frame_reach(x, y));   // uniform branch
             const int limc = max(lim, 1);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
             if (lane == 0) s_bits[c * NWV + wv] = b;
         }
     };
-    if (!cached) load_plane();
+    if (__builtin_expect(!cached, 0)) load_plane();
     else {
         if (tid < plan_nst) s_ent[tid] = plan_ent;      // (at most STRIP_SCHED < 1024 steps)
         if (tid == 0) { s_misc[0] = plan_nst; s_misc[5] = plan_rb; s_misc[6] = plan_re; s_misc[8] = 0; }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         if (lane < n_pad - n_out) s_ent[n_out + lane] = make_uint2(SCH_DRAIN | SCH_IDLE, last_sj);
         if (lane == 0) s_misc[0] = n_pad;
     };
-    if (!cached) {
+    if (__builtin_expect(!cached, 0)) {
         if (wv == 0) {
             make_prefix(true);
             const int rb0 = act_before_cost((int)(((long long)blockIdx.x * tot_cost) / G));
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         const unsigned o = __umul24(slot, P) + lane + 1;
         sA[o] = qa;
         sL[o] = ql;
-        if (!cached) {                                   // (a stored plan knows every window's radius, count and class)
+        if (__builtin_expect(!cached, 0)) {              // (a stored plan knows every window's radius, count and class)
             // land-side cells up to and including the lane's: those of lanes 1 .. lane by mbcnt on the mask shifted down, lane 0's added
             const u64 lm1 = lm >> 1;
             const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(lm1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm1, (unsigned)(lm & 1ull)));
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
             found = valid && nn != 0;
             nn = max(nn, 1);                             // (reads in bounds; the result is not used)
         }
-        if (!cached) {
+        if (__builtin_expect(!cached, 0)) {
             const int ncell = __builtin_amdgcn_readfirstlane(s_misc[1 + buf]);
             const int e = wv * SB_WAVE + lane;
             valid = e < ncell;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
         const unsigned o = (unsigned)y * (unsigned)g.nx + (unsigned)x;     // (fewer than 2^31 cells: check_dims)
         const unsigned rho = (unsigned)(jp * C + ly);    // ring row of the cell
         const unsigned cx = (unsigned)(lx + H + 1);      // its table column
-        if (!cached) {
+        if (__builtin_expect(!cached, 0)) {
             int lim = H;
             if (limited) lim = min(lim, frame_reach(x, y));   // uniform branch
             const int limc = max(lim, 1);
