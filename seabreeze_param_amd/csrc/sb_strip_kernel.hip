@@ -803,7 +803,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
             }
             // (Under the uniform condition, although every other load of the march is unconditional: with this load on
             // every path hipcc 7.2 emitted NO wait at all for the staged blocks' loads in the fp64 kernels -- the
-            // results then hang on timing.  tests/test_build.py checks the waits of every variant in the built library.)
+            // results then hang on timing.  tools/check_waits.py (run by tests/test_abi_and_host.py) checks the waits of every variant in the built library.)
             if (cached) qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
         };
         for (int i = STRIP_DEPTH; i < nst; i += STRIP_DEPTH) {       // nst is a multiple of three
