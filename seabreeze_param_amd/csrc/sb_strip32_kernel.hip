@@ -418,6 +418,9 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
     // S1: one piece of the row -> its ring row (prefix along longitude only).  SEG 0: columns 0 .. 63; 1: columns 64 .. 95
     // (lanes 0 .. 31; the upper lanes carry zeros through the scan and write nothing).
     auto stage = [&](S32Regs<FLY> &R, unsigned slot, int seg) __attribute__((always_inline)) {
+        // (the block's loads have landed once at most two blocks' loads -- two pieces each -- are outstanding: see k_strip)
+        if constexpr (FLY) asm volatile("s_waitcnt vmcnt(16)" : "+v"(R.th), "+v"(R.zz), "+v"(R.sg), "+v"(R.lw) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(R.th), "+v"(R.lw) : : "memory");
         const bool live = seg == 0 || lane < 32;
         const bool land = live && (R.lw & R.lbit) != 0u;
         const u64 lm = __builtin_amdgcn_ballot_w64(land);
@@ -663,7 +666,10 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
         auto step = [&](S32Regs<FLY> &RA, S32Regs<FLY> &RB, unsigned &E, unsigned &J, const unsigned &En, int i, int buf) __attribute__((always_inline)) {
             const unsigned ent = E, sj = J;
 #if defined(SB_STAMPS) && !defined(SB_STAMPS_WIND)
-            if (i < SB_NSTAMP - 5) SB_T(5 + i);          // step i begins (i >= 3)
+            if (i < SB_NSTAMP - 10) SB_T(5 + i);         // step i begins (i >= 3)
+#define SB_TS(k) do { if (i == 12) SB_T(27 + (k)); } while (0)      // the inside of one step (the tenth of the march)
+#else
+#define SB_TS(k) do { } while (0)
 #endif
             entry(i + S32_DEPTH, E, J);                  // (consumed by `issue` below: the read travels under S1)
             const int pos = (int)(ent & 0xffffu);
@@ -687,14 +693,24 @@ __global__ __launch_bounds__(S32_NT) void k_strip32(char *plan, const int *plan_
                 }
                 if (lister) list_cells(strip, jp - qoff, bwd, buf);
             }
-            issue(RA, RB, J);                                     // (the one place of this copy of the step that loads)
+            // The stored list of the NEXT step's query, loaded AHEAD of this step's block loads: the vector-memory counter is
+            // in order, and a list loaded behind them could only be waited for together with them -- every query step then
+            // sat out what was left of the latency of loads meant for three steps later (round 4: 1.4 us per query step).
+            unsigned qn = ~0u;
+            if (cached) qn = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
+            SB_TS(0);                                             // staged
+            issue(RA, RB, J);                                     // (the one place of this copy of the step that loads blocks)
             if (!idle) {
+                SB_TS(1);                                         // loads issued, first barrier reached
                 lds_barrier();
+                SB_TS(2);                                         // ... passed
                 if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf, (ent >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
                 if (!drain && wv >= 8 && wv <= 10) vertical(jp);
+                SB_TS(3);                                         // queries / sums along latitude done
                 lds_barrier();                                    // (the next step writes the ring block this step's queries read)
+                SB_TS(4);                                         // second barrier passed
             }
-            if (cached) qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
+            if (cached) qc = qn;
         };
         // (the statistics are in LDS before the first step reads them: the first real step begins with a restart)
         lds_barrier();

@@ -503,6 +503,13 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
     auto stage = [&](StripRegs<T, FLY> &R, unsigned ent, int jp) __attribute__((always_inline)) {
         sb_cdp kt = (sb_cdp)sb_strip_k;
         asm volatile("" : "+s"(kt));                      // (opaque: with STRIP_KTAB the constants are loaded here, every time)
+        // This block's loads were issued three steps ago, and the two steps since have each issued a block's loads of their
+        // own (`issue` is unconditional) besides lists and stores: once at most two blocks' loads are outstanding -- the
+        // counter is in order -- this block's have landed.  Said explicitly, tied to the registers: hipcc's own count of the
+        // loads in flight has been seen to go wrong at this very place (see the step), and a wait that is missing here
+        // goes unnoticed by every test, three steps being longer than the latency of memory.
+        if constexpr (FLY) asm volatile("s_waitcnt vmcnt(8)" : "+v"(R.th), "+v"(R.zz), "+v"(R.sg), "+v"(R.lw) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(R.th), "+v"(R.lw) : : "memory");
         // Predicates as one compare each, straight into a lane mask (an `a && b` of two of them costs two more vector
         // instructions to re-form the mask): the land-side bit is tested against a per-lane bit that is zero where the
         // cell does not exist.
@@ -795,7 +802,12 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
                 if (!drain) stage(R, ent, jp);
                 if (lister) list_cells(strip, jp - qoff, bwd, buf);
             }
-            issue(R, J);                                          // (the one place of this copy of the step that loads)
+            // The stored list of the NEXT step's query, loaded AHEAD of this step's block loads: the vector-memory counter is
+            // in order, and a list loaded behind them could only be waited for together with them -- a query step then sat
+            // out what was left of the latency of loads meant for three steps later (k_strip32: 1.4 us per query step).
+            unsigned qn = ~0u;
+            if (cached) qn = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
+            issue(R, J);                                          // (the one place of this copy of the step that loads blocks)
             if (!idle) {
                 lds_barrier();
                 if (qany && wv < C / 2) query(pos - qoff, strip, jp - qoff, buf, (ent >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1));
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(STRIP_NT) void k_strip(char *plan, const int *plan_
             // (Under the uniform condition, although every other load of the march is unconditional: with this load on
             // every path hipcc 7.2 emitted NO wait at all for the staged blocks' loads in the fp64 kernels -- the
             // results then hang on timing.  tools/check_waits.py (run by tests/test_abi_and_host.py) checks the waits of every variant in the built library.)
-            if (cached) qc = plan_lists[((En >> SCH_QI_SHIFT) & (SB_PLAN_NQ - 1)) * (unsigned)(SW * C) + qc_off];
+            if (cached) qc = qn;
         };
         for (int i = STRIP_DEPTH; i < nst; i += STRIP_DEPTH) {       // nst is a multiple of three
             step(R0, E0, J0, E1, i, 0);

@@ -13,13 +13,14 @@ sys.path.insert(0, ".")
 from seabreeze_param_amd import hip, synth  # noqa: E402
 
 nx, ny, nz = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (2560, 1920, 8)
-dt = np.float64
+dt = np.float32 if "f32" in sys.argv[4:] else np.float64      # f32 with a window beyond 16 cells: the marks of k_strip32
 st = synth.static_fields(nx, ny, dt)
 ctx = hip.Context()
-if len(sys.argv) > 4 and sys.argv[4] == "replan":     # the planning call's path: no stored plan
+if "replan" in sys.argv[4:]:     # the planning call's path: no stored plan
     ctx.set_plan_cache(False)
 coast = ctx.get_edges(st.landfrac, st.icefrac)
 cdist = ctx.get_dist(coast, st.landfrac, st.lon, st.lat)
+ctx.set_search_radius_hint(hip.dist_window(st.lon, st.lat) + 1)
 p = synth.pressure_3d(st, nz, dt)
 u, v = synth.wind_step(st, nz, 1, dt)
 th = synth.theta_step(st, 1, dt)
@@ -48,12 +49,20 @@ for w in (0, 15):
           f"first issue {np.mean(t[:, w, 30] - t[:, w, 29]):.2f}, two more {np.mean(t[:, w, 31] - t[:, w, 30]):.2f}, statistics {np.mean(t[:, w, 4] - t[:, w, 31]):.2f}")
 # steps: time between the beginnings of consecutive steps, wave 0, by step number
 print("step i begins -> step i + 1 begins, us (wave 0 | wave 15), mean over the workgroups that have the step")
-for i in range(0, NS - 9):
+for i in range(0, NS - (14 if 'f32' in sys.argv[4:] else 9)):
     a, b = t[:, :, 8 + i], t[:, :, 9 + i]
     ok = (b > a) & (a >= t[:, :, 4]) & (b <= t[:, :, 5] + 1e-9)
     if ok[:, 0].sum() == 0:
         break
     print(f"   step {i:2d}: n {int(ok[:, 0].sum()):3d}   {np.mean((b - a)[:, 0][ok[:, 0]]):.2f} | {np.mean((b - a)[:, 15][ok[:, 15]]) if ok[:, 15].any() else float('nan'):.2f}")
+if "f32" in sys.argv[4:]:
+    # k_strip32: the inside of the march's tenth step (marks 27..31), by wave: queries on waves 0-7, sums along latitude on 8-10
+    have = (t[:, 0, 31] > 0) & (t[:, 0, 27] > 0)
+    print(f"inside step 12 ({int(have.sum())} workgroups): wave: step begin -> staged | -> barrier reached | barrier wait | queries or sums | second barrier wait")
+    for w in (0, 3, 7, 8, 10, 12, 15):
+        a = t[have][:, w, :]
+        b0 = a[:, 5 + 12]
+        print(f"   wave {w:2d}: {np.mean(a[:, 27] - b0):.2f} | {np.mean(a[:, 28] - a[:, 27]):.2f} | {np.mean(a[:, 29] - a[:, 28]):.2f} | {np.mean(a[:, 30] - a[:, 29]):.2f} | {np.mean(a[:, 31] - a[:, 30]):.2f}")
 life = t[:, :, 7].max(axis=1) - t[:, :, 0].min(axis=1)
 print(f"workgroup life: mean {life.mean():.2f} max {life.max():.2f} min {life.min():.2f} us; march (wave 0) mean {np.mean(t[:, 0, 5] - t[:, 0, 4]):.2f} max {np.max(t[:, 0, 5] - t[:, 0, 4]):.2f}")
 # what a workgroup's life is made of: its steps by kind, from the stored plan; least squares
